@@ -174,11 +174,16 @@ def shard_save(shards_dir, shard_id, dim, centroid_ids, centroid_vecs, lists):
     off = np.zeros(nl + 1, dtype=np.uint64)
     for i, l in enumerate(lists):
         off[i + 1] = off[i] + len(l[0])
-    cat = lambda j, dt: np.ascontiguousarray(
-        np.concatenate([np.asarray(l[j], dtype=dt).reshape(len(l[0]), -1) for l in lists], axis=0)
-        if nl else np.zeros((0, 1), dtype=dt), dtype=dt)
-    ids, eids, tss = cat(0, np.uint64), cat(1, np.uint64), cat(2, np.uint64)
-    vecs = cat(3, np.float32) if nl and off[-1] > 0 else np.zeros((0, dim), dtype=np.float32)
+    tot = int(off[-1])
+    ids = np.zeros(tot, dtype=np.uint64)
+    eids = np.zeros(tot, dtype=np.uint64)
+    tss = np.zeros(tot, dtype=np.uint64)
+    vecs = np.zeros((tot, dim), dtype=np.float32)
+    for i, l in enumerate(lists):
+        a, b = int(off[i]), int(off[i + 1])
+        if b > a:
+            ids[a:b], eids[a:b], tss[a:b] = l[0], l[1], l[2]
+            vecs[a:b] = np.asarray(l[3], dtype=np.float32).reshape(b - a, dim)
     cids = np.ascontiguousarray(centroid_ids, dtype=np.uint64)
     cv = f32c(np.asarray(centroid_vecs, dtype=np.float32).reshape(nl, dim))
     return lib().orc_shard_save_to(shards_dir.encode(), shard_id, dim, nl, _p(cids), _p(cv), _p(off),
