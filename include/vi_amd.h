@@ -1,0 +1,207 @@
+/*
+ * vi_amd.h — C ABI of libvi_amd.so, the MI355X-native (gfx950) implementation of the
+ * distance hot path of NirajNair/vector-indexer.
+ *
+ * The reference is a pure-Rust crate with no FFI seam; the entry points below are the
+ * calls its Rust host code (src/api.rs, src/ivf_index.rs, src/kmeans.rs) would bind
+ * through `extern "C"` to move that path onto the GPU.  Each declaration cites the
+ * reference interface it replaces (file:line relative to the reference repo).  The Rust
+ * and Python bindings a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes, caller-allocated outputs, no exceptions/panics cross the ABI
+ *   - every function returns a vi_status; vi_last_error() gives the thread-local message
+ *   - vi_status mirrors the std::io::ErrorKind values the reference returns
+ *   - all arrays are row-major contiguous, f32 / u64 / i64 little-endian host memory unless a
+ *     parameter says "device"
+ *   - a vi_indexer handle may be shared by several host threads (search is serialised
+ *     internally per handle; the reference's search is &self, ivf_index_tests.rs:768-807)
+ */
+#ifndef VI_AMD_H
+#define VI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VI_AMD_ABI_VERSION 1
+
+typedef enum vi_status {
+  VI_OK = 0,
+  VI_ERR_INVALID_INPUT = 1, /* io::ErrorKind::InvalidInput (api.rs:116-134,192-201; ivf_index.rs:197-202) */
+  VI_ERR_NOT_FOUND = 2,     /* io::ErrorKind::NotFound (missing index.bin; shards.rs:257-265) */
+  VI_ERR_INVALID_DATA = 3,  /* io::ErrorKind::InvalidData (shards.rs:215-231,310-316) */
+  VI_ERR_OTHER = 4,         /* io::ErrorKind::Other (bincode wrap ivf_index.rs:280,312; shards.rs:193-213) */
+  VI_ERR_IO = 5,            /* any other raw std::fs error */
+  VI_ERR_PANIC = 6,         /* the reference would panic here (NaN in partial_cmp().unwrap(), ivf_index.rs:215,265) */
+  VI_ERR_DEVICE = 7         /* no MI355X / HIP failure: the product never falls back to the CPU */
+} vi_status;
+
+/* Thread-local, NUL-terminated description of the last failure on this thread. */
+const char *vi_last_error(void);
+uint32_t vi_abi_version(void);
+/* Number of visible HIP devices (0 on a CPU-only box; never an error). */
+int vi_device_count(void);
+
+/* ---- heuristics ------------------------------------------------------------------- */
+/* replaces calculate_num_clusters — src/utils.rs:9-16 */
+uint64_t vi_calculate_num_clusters(uint64_t num_vectors);
+/* replaces calculate_max_iterations — src/utils.rs:18-26 */
+uint64_t vi_calculate_max_iterations(uint64_t num_vectors);
+/* mini-batch size rule — src/kmeans.rs:83 */
+uint64_t vi_minibatch_size(uint64_t num_vectors);
+
+/* ---- distance kernels ------------------------------------------------------------- */
+typedef enum vi_sum_order {
+  VI_ORDER_SCALAR = 0, /* euclidean_distance_squared — src/utils.rs:28-30 (search path) */
+  VI_ORDER_LANES = 1   /* compute_distance_simd — src/kmeans.rs:377-419 (k-means path) */
+} vi_sum_order;
+
+/* out[i] = squared L2 between a[i,:] and b[i,:], n pairs of dimension d, computed on the
+ * GPU with the reference's exact f32 summation order (bit-identical results). */
+vi_status vi_l2sq_pairs(const float *a, const float *b, uint64_t n, uint32_t d, vi_sum_order order,
+                        float *out);
+
+/* ---- k-means ---------------------------------------------------------------------- */
+typedef enum vi_assign_mode {
+  /* reference behaviour: k <= 100 brute force, k > 100 hierarchical (approximate)
+   * — assign_points_simd_parallel, src/kmeans.rs:445-459 */
+  VI_ASSIGN_REFERENCE = 0,
+  /* extension: exact nearest centroid for every k (MFMA -2·X·Cᵀ+‖c‖² filter + exact-order
+   * re-check); equals assign_points_brute_force (src/kmeans.rs:462-470) bit for bit */
+  VI_ASSIGN_EXACT = 1
+} vi_assign_mode;
+
+/* replaces assign_points_simd_parallel(&X,&C,&mut labels,seed) — src/kmeans.rs:445-450.
+ * labels: n u64 (Rust usize).  dist_out (optional, n f32): lane-order distance to the label. */
+vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint64_t k, uint64_t seed,
+                    vi_assign_mode mode, uint64_t *labels, float *dist_out);
+
+/* replaces run_kmeans_mini_batch(&data,k,max_iters,early_stop_threshold,seed)
+ * — src/kmeans.rs:64-70.  early_stop_threshold < 0 means None (=> 1e-4).
+ * centroids_out: k x d, labels_out: n.  iters_run optional.
+ * Empty input => VI_ERR_INVALID_INPUT (kmeans.rs:72-77). */
+vi_status vi_kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters,
+                               float early_stop_threshold, uint64_t seed, vi_assign_mode mode,
+                               float *centroids_out, uint64_t *labels_out, uint64_t *iters_run);
+
+/* replaces run_kmeans_parallel(...) — src/kmeans.rs:15-21 (same shape as above). */
+vi_status vi_kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters,
+                             float early_stop_threshold, uint64_t seed, vi_assign_mode mode,
+                             float *centroids_out, uint64_t *labels_out, uint64_t *iters_run);
+
+/* ---- shard files ------------------------------------------------------------------ */
+/* replaces Shard::save_to(&self, shards_dir) — src/shards.rs:68-177.  Lists flattened:
+ * list i owns vectors [list_off[i], list_off[i+1]).  Byte-identical file layout. */
+vi_status vi_shard_save_to(const char *shards_dir, uint64_t shard_id, uint32_t dim, uint32_t num_lists,
+                           const uint64_t *centroid_ids, const float *centroid_vecs,
+                           const uint64_t *list_off, const uint64_t *ids, const uint64_t *ext_ids,
+                           const uint64_t *timestamps, const float *vecs);
+
+/* replaces Shard::get_centroid_vectors_from(shards_dir, shard_id, &centroid_ids)
+ * — src/shards.rs:188-349.  Call once with the output buffers NULL to get counts[i]
+ * (vectors in requested list i) and *dim_out, then again with buffers:
+ * centroid_out n_req x dim; metas_out 3 u64 {id, external_id, timestamp} per vector;
+ * vecs_out dim f32 per vector, in request order. */
+vi_status vi_shard_get_centroid_vectors_from(const char *shards_dir, uint64_t shard_id,
+                                             const uint64_t *centroid_ids, uint64_t n_req,
+                                             uint32_t *dim_out, uint64_t *counts, float *centroid_out,
+                                             uint64_t *metas_out, float *vecs_out);
+
+/* ---- VectorIndexer (src/api.rs) ---------------------------------------------------- */
+/* mirrors VectorIndexerConfig — src/api.rs:8-54 — plus clearly marked extensions */
+typedef struct vi_config {
+  uint32_t dimension;
+  const char *index_dir;    /* NULL => "index"  (api.rs:36) */
+  const char *shards_dir;   /* NULL => "shards" (api.rs:37) */
+  uint64_t default_k;       /* 10      (api.rs:38) */
+  uint64_t default_n_probe; /* 20      (api.rs:39) */
+  uint64_t max_k;           /* 10 000  (api.rs:40) */
+  uint64_t max_n_probe;     /* 10 000  (api.rs:41) */
+  /* --- extensions (all zero = reference behaviour) --- */
+  uint64_t nlist_override;  /* 0 => calculate_num_clusters(N) (ivf_index.rs:59) */
+  uint64_t seed;            /* 0 => 42 (api.rs:143,183) */
+  int32_t assign_mode;      /* vi_assign_mode for the build's final assignment */
+  int32_t device;           /* HIP device ordinal */
+  /* multi-GPU partition: this process keeps only the inverted lists of shards s with
+   * s % world_size == rank resident (coarse table replicated).  world_size 0/1 => all. */
+  int32_t rank;
+  int32_t world_size;
+  uint64_t now_secs;        /* 0 => wall clock; else value used for timestamp==0 records
+                               (vector_store.rs:36-40) */
+} vi_config;
+
+/* VectorIndexerConfig::new(dimension) — src/api.rs:33-43 */
+void vi_config_init(vi_config *cfg, uint32_t dimension);
+
+typedef struct vi_indexer vi_indexer;
+
+/* VectorIndexer::new(cfg) — src/api.rs:103-106 */
+vi_status vi_indexer_new(const vi_config *cfg, vi_indexer **out);
+/* VectorIndexer::load(cfg) — src/api.rs:109-112 (+ uploads the lists to HBM) */
+vi_status vi_indexer_load(const vi_config *cfg, vi_indexer **out);
+/* VectorIndexer::build_from_records(self, records) — src/api.rs:115-146.
+ * values: n x dimension; ext_ids: n (NULL => 0..n-1); timestamps: n (NULL or 0 => now).
+ * dims (optional, n): per-record length, to reproduce the "vector dimension mismatch at
+ * index {i}" error (api.rs:122-133); NULL => all equal cfg.dimension. */
+vi_status vi_indexer_build_from_records(vi_indexer *ix, const uint64_t *ext_ids, const float *values,
+                                        const uint64_t *timestamps, const uint32_t *dims, uint64_t n);
+/* VectorIndexer::build_from_vector_file(self, path) — src/api.rs:149-186 */
+vi_status vi_indexer_build_from_vector_file(vi_indexer *ix, const char *vector_file);
+
+/* VectorIndexer::search(&self, SearchRequest) — src/api.rs:188-222 — batched over nq queries
+ * (extension: the reference takes one query per call; bindings/python/src/lib.rs:74-97 loops).
+ * k and n_probe are clamped to max_k / max_n_probe first (api.rs:189-190), then k==0 or
+ * n_probe==0 => VI_ERR_INVALID_INPUT (ivf_index.rs:197-202); query_dim != dimension =>
+ * VI_ERR_INVALID_INPUT (api.rs:192-201).
+ * Outputs (row stride = clamped k, which is returned in *k_out if non-NULL):
+ *   D  nq x k f32 squared-L2, padded +inf     (lib.rs:179-187)
+ *   I  nq x k i64 external ids, padded -1
+ *   V  optional nq x k x dimension f32 (include_vectors; api.rs:213-217), zero padded
+ *   counts optional nq: results actually found per query */
+vi_status vi_indexer_search(const vi_indexer *ix, const float *queries, uint64_t nq, uint32_t query_dim,
+                            uint64_t k, uint64_t n_probe, float *D, int64_t *I, float *V,
+                            uint64_t *counts, uint64_t *k_out);
+
+/* Same search, but queries/D/I are DEVICE pointers on the indexer's GPU and nothing is copied
+ * to the host; tie (optional, nq x k u64) receives the reference candidate-order key
+ * ((shard-visit-order<<32)|position) needed to merge per-GPU partial results exactly.
+ * Used by the multi-GPU path (all-gather of per-rank top-k over RCCL). */
+vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq,
+                                   uint64_t k, uint64_t n_probe, float *D_dev, int64_t *I_dev,
+                                   uint64_t *tie_dev);
+
+/* Merge `parts` per-rank partial results (each nq x k, device pointers laid out
+ * [part][nq][k]) into the global top-k with the reference's stable order. */
+vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts,
+                                   const float *D_parts, const int64_t *I_parts,
+                                   const uint64_t *tie_parts, float *D_out, int64_t *I_out);
+
+/* accessors */
+uint32_t vi_indexer_dimension(const vi_indexer *ix);
+uint64_t vi_indexer_num_centroids(const vi_indexer *ix);
+uint64_t vi_indexer_num_vectors(const vi_indexer *ix); /* resident on this rank */
+uint64_t vi_indexer_num_shards(const vi_indexer *ix);
+/* centroids (k' x dim) and centroids_to_shard (k') of the loaded index */
+vi_status vi_indexer_centroids(const vi_indexer *ix, float *centroids_out, uint64_t *c2s_out);
+void vi_indexer_free(vi_indexer *ix);
+
+/* ---- instrumentation (bench.py / profiling) ---------------------------------------- */
+typedef struct vi_search_stats {
+  uint64_t nq, k, n_probe_eff;
+  uint64_t coarse_candidates;  /* nq * k' */
+  uint64_t scanned_vectors;    /* Σ over queries of Σ len(probed lists resident here) */
+  uint64_t scan_items;         /* (list, query-group) work items of the list-scan kernel */
+  float ms_total, ms_coarse, ms_group, ms_scan, ms_merge; /* HIP-event times on the search stream */
+} vi_search_stats;
+/* stats of the most recent search on this handle (timing collected only if enabled) */
+vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out);
+void vi_indexer_enable_timing(vi_indexer *ix, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VI_AMD_H */

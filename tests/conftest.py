@@ -14,6 +14,11 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    try:  # cheap probe through the product library (no torch import)
+        from vector_indexer_py import _native
+        return _native.lib().vi_device_count() > 0
+    except Exception:
+        pass
     try:
         import torch
         return torch.cuda.is_available()

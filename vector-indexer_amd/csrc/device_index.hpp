@@ -1,0 +1,117 @@
+// device_index.hpp — HBM-resident IVF index and the search pipeline entry points.
+//
+// HBM layout ("lane-interleaved blocks").  Every vector set that gets scanned — the coarse
+// centroid table and each inverted list — is stored in blocks of 64 vectors:
+//
+//     block[b] : float4 [dq][64]          dq = ceil(dim/4), zero padded
+//     element (qd, lane).{x,y,z,w} = dims 4*qd .. 4*qd+3 of vector (64*b + lane)
+//
+// so that a wave64 reading quad qd of a block issues ONE global_load_dwordx4 covering a
+// contiguous, 1 KiB-aligned span: lane = vector, registers = consecutive dimensions.  That
+// makes the reference's strictly sequential f32 sum over d (src/utils.rs:28-30) a per-lane
+// register chain with perfectly coalesced loads, and lets one loaded quad be reused by a
+// whole group of queries from registers.  Lists are padded to whole blocks (pad lanes carry
+// zeros and are masked by the list length).  External ids live in a parallel u64 array
+// indexed by slot = 64*block + lane.  The AoS record layout of the shard files
+// (24 B meta + 4·D B + pad, shards.rs:106-114) is kept only on disk.
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "shards.hpp"
+
+namespace vi {
+
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;   // empty slot marker in a sorted run
+constexpr uint32_t kMaxSelect = 64;        // wave-resident top-k width of the fast path
+
+struct BlockSet {               // a set of lists stored as lane-interleaved blocks
+  DevBuf<float> blocks;         // [nblocks][dq][64][4]
+  uint32_t dq = 0;
+  uint64_t nblocks = 0;
+};
+
+struct SearchWorkspace {
+  DevBuf<float> q;              // queries on device (nq x dim) when the caller passed host memory
+  DevBuf<float> crun_dist;      // coarse partial runs [nq][S][P]
+  DevBuf<uint32_t> crun_pos;
+  DevBuf<uint32_t> probes;      // [nq][P] list ids in probe-rank order
+  DevBuf<uint32_t> gorder;      // [nq][P] candidate-order rank of each probe (shard visiting order)
+  DevBuf<uint32_t> cnt;         // [nlists] (#queries probing list) ; cursor = second half
+  DevBuf<uint32_t> seg_start;   // [nlists+1]
+  DevBuf<uint32_t> item_start;  // [nlists+1]
+  DevBuf<uint32_t> pairs;       // [nq*P] slot ids grouped by list
+  DevBuf<float> run_dist;       // [nq*P][K]
+  DevBuf<uint32_t> run_pos;
+  DevBuf<float> D;              // outputs when the caller wants host results
+  DevBuf<int64_t> I;
+  DevBuf<uint64_t> tie;
+  DevBuf<uint64_t> slots;       // [nq][k] global slot of each result (include_vectors gather)
+  DevBuf<uint32_t> counts;      // [nq]
+  DevBuf<uint64_t> stats;       // device-side counters
+  DevBuf<float> V;
+  // generic (large k / n_probe) path
+  DevBuf<uint64_t> sort_keys;
+  DevBuf<uint32_t> cand_off;
+};
+
+struct DeviceIndex {
+  int device = 0;
+  int order = VI_ORDER_SCALAR;  // summation order of every distance this index computes
+  uint32_t dim = 0, dq = 0;
+  uint64_t nlists = 0;          // k' (non-empty centroids of the index)
+  uint64_t nvec_resident = 0;   // vectors whose lists are resident on this GPU
+  uint64_t nshards = 0;
+  BlockSet centroids;           // the coarse table as one list of k' vectors
+  BlockSet lists;               // all resident inverted lists back to back
+  DevBuf<uint32_t> list_first_block;  // [nlists]
+  DevBuf<uint32_t> list_len;          // [nlists]  (0 => not resident here / empty)
+  DevBuf<uint32_t> list_shard;        // [nlists]
+  DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  mutable std::mutex mu;              // one search at a time per handle
+  mutable SearchWorkspace ws;
+  mutable vi_search_stats stats{};
+  bool timing = false;
+
+  ~DeviceIndex();
+};
+
+// Upload: centroid table + resident lists (shards with shard % world == rank), repacked on the GPU.
+vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir, int device, int rank,
+                            int world, DeviceIndex *out);
+
+struct SearchIO {
+  const float *queries = nullptr;  // host or device (queries_on_device)
+  bool on_device = false;          // queries and D/I/tie are device pointers
+  uint64_t nq = 0, k = 0, n_probe = 0;
+  float *D = nullptr;
+  int64_t *I = nullptr;
+  uint64_t *tie = nullptr;
+  float *V = nullptr;              // host only
+  uint64_t *counts = nullptr;      // host only
+};
+vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io);
+
+// Build a device index from device-resident arrays (used by the k-means path, where the
+// "index" is the two-level centroid hierarchy of assign_points_hierarchical, kmeans.rs:474-581,
+// and by the GPU list build).  table: ntable x dim row-major (device) = coarse table;
+// rows: row-major device matrix the lists draw from; list_off[nlists+1] (host) delimits
+// member_rows (host, row index per list member, list order = scan order); ids (device,
+// optional) = external id per row (null => row index); list_shard (host, optional).
+vi_status device_index_from_rows(int device, int order, uint32_t dim, const float *table_dev, uint64_t ntable,
+                                 const float *rows_dev, const std::vector<uint64_t> &list_off,
+                                 const std::vector<uint32_t> &member_rows, const uint64_t *ids_dev,
+                                 const std::vector<uint32_t> *list_shard, DeviceIndex *out);
+
+vi_status merge_partials_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const float *D_parts,
+                                const int64_t *I_parts, const uint64_t *tie_parts, float *D_out,
+                                int64_t *I_out);
+
+vi_status l2sq_pairs_device(const float *a, const float *b, uint64_t n, uint32_t d, int order, float *out);
+
+}  // namespace vi

@@ -1,0 +1,40 @@
+// scan.hpp — launchers of the exact-order scan / select / repack kernels shared by the
+// search path (search_kernels.hip) and the k-means path (kmeans.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.hpp"
+
+namespace vi {
+
+struct ScanArgs {
+  const float4 *blocks;   // lane-interleaved blocks (device_index.hpp)
+  uint32_t dq, dim;
+  const float *Q;         // nq x dim, row-major, device
+  uint32_t nq;
+  uint32_t K;             // entries per output run (<= 64)
+  float *run_dist;        // [slots][K]
+  uint32_t *run_pos;
+  // COARSE: one table of nvec vectors split into S ranges of bps blocks; slot = q*S + split
+  uint32_t nvec, S, bps;
+  // LISTS: items derived from the grouping arrays; slot = pairs[...] = q*P + rank
+  const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs;
+  uint32_t nlists, P;
+};
+
+// query-group width for a unit (table or list) probed by `avg_queries_per_unit` queries
+int pick_qg(uint32_t dq, double avg_queries_per_unit, int order);
+vi_status launch_scan(const ScanArgs &a, int qg, int order, bool coarse, uint32_t nitems_upper, hipStream_t st);
+// COARSE-mode split of a table of nblk blocks for nq queries: returns S and sets *bps
+uint32_t coarse_splits(uint64_t nq, int qg, uint32_t nblk, uint32_t *bps);
+
+// Rows of a row-major device matrix -> lane-interleaved blocks.  row_of_slot[s] = source row
+// of destination slot s (slot = 64*block + lane) or ~0u for a pad lane.  ids_out (optional)
+// receives id_of_row[row] (or the row index itself when id_of_row is null).
+vi_status launch_repack_rows(const float *src, uint32_t dim, uint32_t dq, const uint32_t *row_of_slot,
+                             uint64_t nslots, const uint64_t *id_of_row, float *blocks, uint64_t *ids_out,
+                             hipStream_t st);
+
+}  // namespace vi

@@ -1,0 +1,1066 @@
+// search_kernels.hip — gfx950 kernels of the IVF search path and their host-side pipeline.
+//
+// Reference path being replaced: IvfIndex::search_with_paths (src/ivf_index.rs:190-267):
+//   coarse  : euclidean_distance_squared(q, c_i) for all centroids, stable sort, take n_probe
+//   scan    : euclidean_distance_squared(q, v) for every vector of the probed lists
+//   select  : stable sort of all candidates, take k
+// with euclidean_distance_squared = strictly sequential f32 sum of (x-y)^2 (src/utils.rs:28-30).
+//
+// GPU formulation (all distances are computed in the reference's exact summation order, so
+// ids AND distances are bit-identical; nothing is re-ranked):
+//   scan_kernel<COARSE>   one wave = (group of QG queries) x (range of centroid blocks);
+//                         lane = centroid, per-lane sequential f32 chain over d; wave-resident
+//                         sorted top-P list per query (DPP shift insertion)
+//   coarse_merge_kernel   one wave per query: S sorted partial runs -> probe list, shard
+//                         visiting order, histogram of probed lists
+//   group_*_kernel        counting sort of (query,probe) pairs by list  => every list block is
+//                         streamed once per group of QG queries that probe it
+//   scan_kernel<LISTS>    one wave = (list) x (group of <= QG queries probing it)
+//   final_merge_kernel    one wave per query: P sorted runs -> top-k, ids, tie keys
+//
+// Compiled with -ffp-contract=off: a fused multiply-add would change the rounding of
+// acc + t*t and break bit parity with the reference.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "device_index.hpp"
+#include "scan.hpp"
+
+namespace vi {
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = kWave * kWavesPerBlock;
+
+// ------------------------------------------------------------------------------------------
+// wave primitives
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+// value of lane-1 (DPP wave_shr:1); lane 0 receives `fill`
+__device__ __forceinline__ float shr1_f(float v, float fill) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t shr1_u(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    const uint64_t t = ((uint64_t)hi << 32) | lo;
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-resident sorted top-K (K <= 64): lane i holds the i-th best (dist, pos) pair in
+// ascending (dist, pos) order.  `thr`/`thrp` cache entry K-1 (wave-uniform).
+// ------------------------------------------------------------------------------------------
+struct WaveTopK {
+  float d;
+  uint32_t p;
+  float thr;
+  uint32_t thrp;
+  __device__ __forceinline__ void init() {
+    d = INFINITY; p = kNoPos; thr = INFINITY; thrp = kNoPos;
+  }
+  // Offer one candidate per lane (dist, pos); pos == kNoPos marks an invalid lane.
+  // Candidates beat entry K-1 iff (dist,pos) < (thr,thrp) lexicographically.
+  __device__ __forceinline__ void offer(float dist, uint32_t pos, int K) {
+    bool pass = (dist < thr) || (dist == thr && pos < thrp);
+    uint64_t mask = __ballot(pass);
+    while (mask) {
+      const int src = __builtin_ctzll(mask);
+      const float cd = readlane_f(dist, src);
+      const uint32_t cp = readlane_u(pos, src);
+      // entries greater than the candidate shift one lane to the right
+      const bool gt = (d > cd) || (d == cd && p > cp);
+      const float ud = shr1_f(d, -INFINITY);
+      const uint32_t up = shr1_u(p, 0u);
+      const bool ugt = (ud > cd) || (ud == cd && up > cp);
+      d = gt ? (ugt ? ud : cd) : d;
+      p = gt ? (ugt ? up : cp) : p;
+      thr = readlane_f(d, K - 1);
+      thrp = readlane_u(p, K - 1);
+      pass = (dist < thr) || (dist == thr && pos < thrp);
+      const uint64_t rest = (src == 63) ? 0ull : (~0ull << (src + 1));
+      mask = __ballot(pass) & rest;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Exact-order accumulators.  SCALAR: src/utils.rs:28-30.  LANES: src/kmeans.rs:377-419
+// (8-lane chunks, then one 4-lane chunk, then a scalar tail; reduce order see oracle header).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sq_add(float &acc, float q, float x) {
+  const float t = q - x;
+  acc = acc + t * t;  // -ffp-contract=off: separate v_mul_f32 / v_add_f32
+}
+
+template <int QG>
+__device__ __forceinline__ void accumulate_scalar(const float4 *__restrict__ vb, const float4 *lq,
+                                                  uint32_t dq, float (&out)[QG]) {
+  float acc[QG];
+#pragma unroll
+  for (int j = 0; j < QG; ++j) acc[j] = 0.0f;
+#pragma unroll 4
+  for (uint32_t qd = 0; qd < dq; ++qd) {
+    const float4 x = vb[(size_t)qd * kWave];
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const float4 q = lq[j * dq + qd];
+      sq_add(acc[j], q.x, x.x);
+      sq_add(acc[j], q.y, x.y);
+      sq_add(acc[j], q.z, x.z);
+      sq_add(acc[j], q.w, x.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < QG; ++j) out[j] = acc[j];
+}
+
+template <int QG>
+__device__ __forceinline__ void accumulate_lanes(const float4 *__restrict__ vb, const float4 *lq,
+                                                 uint32_t dq, uint32_t dim, float (&out)[QG]) {
+  float a8[QG][8];
+#pragma unroll
+  for (int j = 0; j < QG; ++j)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) a8[j][l] = 0.0f;
+  const uint32_t n8 = dim / 8;
+#pragma unroll 2
+  for (uint32_t c = 0; c < n8; ++c) {
+    const float4 x0 = vb[(size_t)(2 * c) * kWave];
+    const float4 x1 = vb[(size_t)(2 * c + 1) * kWave];
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const float4 q0 = lq[j * dq + 2 * c];
+      const float4 q1 = lq[j * dq + 2 * c + 1];
+      sq_add(a8[j][0], q0.x, x0.x); sq_add(a8[j][1], q0.y, x0.y);
+      sq_add(a8[j][2], q0.z, x0.z); sq_add(a8[j][3], q0.w, x0.w);
+      sq_add(a8[j][4], q1.x, x1.x); sq_add(a8[j][5], q1.y, x1.y);
+      sq_add(a8[j][6], q1.z, x1.z); sq_add(a8[j][7], q1.w, x1.w);
+    }
+  }
+  uint32_t qd = 2 * n8;
+  uint32_t rem = dim - 8 * n8;
+  float a4[QG][4], tail[QG];
+#pragma unroll
+  for (int j = 0; j < QG; ++j) { a4[j][0] = a4[j][1] = a4[j][2] = a4[j][3] = 0.0f; tail[j] = 0.0f; }
+  if (rem >= 4) {  // one f32x4 chunk (kmeans.rs:399-408)
+    const float4 x = vb[(size_t)qd * kWave];
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const float4 q = lq[j * dq + qd];
+      sq_add(a4[j][0], q.x, x.x); sq_add(a4[j][1], q.y, x.y);
+      sq_add(a4[j][2], q.z, x.z); sq_add(a4[j][3], q.w, x.w);
+    }
+    qd += 1;
+    rem -= 4;
+  }
+  if (rem > 0) {  // scalar tail (kmeans.rs:411-416); zero padding adds exact +0
+    const float4 x = vb[(size_t)qd * kWave];
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const float4 q = lq[j * dq + qd];
+      sq_add(tail[j], q.x, x.x); sq_add(tail[j], q.y, x.y);
+      sq_add(tail[j], q.z, x.z); sq_add(tail[j], q.w, x.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < QG; ++j) {
+    const float lo = ((a8[j][0] + a8[j][1]) + a8[j][2]) + a8[j][3];
+    const float hi = ((a8[j][4] + a8[j][5]) + a8[j][6]) + a8[j][7];
+    const float r8 = lo + hi;
+    const float r4 = ((a4[j][0] + a4[j][1]) + a4[j][2]) + a4[j][3];
+    out[j] = (r8 + r4) + tail[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// scan kernel
+// ------------------------------------------------------------------------------------------
+template <int QG, int ORDER, bool COARSE>
+__global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
+  extern __shared__ float4 smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  float4 *lq = smem + (size_t)wave * QG * a.dq;
+  const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
+
+  uint32_t nqi, b0, b1, len, fb;
+  uint32_t slot[QG], qid[QG];
+  if (COARSE) {
+    const uint32_t nqg = (a.nq + QG - 1) / QG;
+    if (item >= nqg * a.S) return;
+    const uint32_t qc = item / a.S, sp = item - qc * a.S;
+    const uint32_t q0 = qc * QG;
+    nqi = min((uint32_t)QG, a.nq - q0);
+#pragma unroll
+    for (int j = 0; j < QG; ++j) { qid[j] = q0 + j; slot[j] = (q0 + j) * a.S + sp; }
+    const uint32_t nblk = (a.nvec + kWave - 1) / kWave;
+    b0 = sp * a.bps;
+    b1 = min(nblk, b0 + a.bps);
+    fb = 0;
+    len = a.nvec;
+  } else {
+    const uint32_t nitems = a.item_start[a.nlists];
+    if (item >= nitems) return;
+    // largest l with item_start[l] <= item  (lists with no items have equal neighbours)
+    uint32_t lo = 0, hi = a.nlists;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
+    const uint32_t j0 = (item - a.item_start[l]) * QG;
+    nqi = min((uint32_t)QG, cnt - j0);
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const uint32_t s = (j < (int)nqi) ? a.pairs[s0 + j0 + j] : 0u;
+      slot[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+      qid[j] = slot[j] / a.P;
+    }
+    len = a.list_len[l];
+    fb = a.first_block[l];
+    b0 = 0;
+    b1 = (len + kWave - 1) / kWave;
+  }
+
+  // stage the group's queries in this wave's LDS slice, zero padded to dq*4 floats
+  {
+    float *lqf = reinterpret_cast<float *>(lq);
+    const uint32_t dpad = a.dq * 4;
+#pragma unroll
+    for (int j = 0; j < QG; ++j) {
+      const float *src = a.Q + (size_t)qid[j] * a.dim;
+      const bool live = j < (int)nqi;
+      for (uint32_t e = lane; e < dpad; e += kWave) lqf[j * dpad + e] = (live && e < a.dim) ? src[e] : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  WaveTopK sel[QG];
+#pragma unroll
+  for (int j = 0; j < QG; ++j) sel[j].init();
+  const int K = (int)a.K;
+
+  for (uint32_t b = b0; b < b1; ++b) {
+    const float4 *vb = a.blocks + ((size_t)(fb + b) * a.dq) * kWave + lane;
+    float dist[QG];
+    if (ORDER == VI_ORDER_SCALAR) accumulate_scalar<QG>(vb, lq, a.dq, dist);
+    else accumulate_lanes<QG>(vb, lq, a.dq, a.dim, dist);
+    const uint32_t pos = b * kWave + lane;
+    const bool valid = pos < len;
+    const uint32_t p = valid ? pos : kNoPos;
+#pragma unroll
+    for (int j = 0; j < QG; ++j)
+      if (j < (int)nqi) sel[j].offer(valid ? dist[j] : INFINITY, p, K);
+  }
+
+  if (lane < K) {
+#pragma unroll
+    for (int j = 0; j < QG; ++j)
+      if (j < (int)nqi) {
+        a.run_dist[(size_t)slot[j] * K + lane] = sel[j].d;
+        a.run_pos[(size_t)slot[j] * K + lane] = sel[j].p;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// coarse merge: S sorted runs per query -> probes (rank order), shard visiting order, histogram
+// ------------------------------------------------------------------------------------------
+struct CoarseMergeArgs {
+  const float *run_dist;
+  const uint32_t *run_pos;
+  uint32_t nq, S, P;              // P = entries per run = probes per query (<= 64), S <= 64
+  const uint32_t *list_shard, *list_len;
+  uint32_t *probes, *gorder, *cnt;
+};
+
+__global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMergeArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t q = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (q >= a.nq) return;
+  const size_t base = ((size_t)q * a.S + lane) * a.P;
+  uint32_t head = 0;
+  float hd = INFINITY;
+  uint32_t hp = kNoPos;
+  if (lane < (int)a.S) { hd = a.run_dist[base]; hp = a.run_pos[base]; }
+  uint32_t mylist = kNoPos;
+  uint32_t found = 0;
+  for (uint32_t i = 0; i < a.P; ++i) {
+    // key = (dist, centroid index): stable sort over index order (ivf_index.rs:205-215)
+    const uint64_t key = (hp == kNoPos) ? ~0ull : (((uint64_t)__float_as_uint(hd) << 32) | hp);
+    const uint64_t m = wave_min_u64(key);
+    if (m == ~0ull) break;
+    if ((uint32_t)lane == i) mylist = (uint32_t)m;
+    if (key == m) {
+      ++head;
+      if (head < a.P) { hd = a.run_dist[base + head]; hp = a.run_pos[base + head]; }
+      else hp = kNoPos;
+    }
+    ++found;
+  }
+  // shard visiting order = first appearance in the probe list; candidate order of probe i is
+  // its rank under the key (first_appearance(shard_i), i)
+  const bool live = (uint32_t)lane < found;
+  const uint32_t shard = live ? a.list_shard[mylist] : kNoPos;
+  uint32_t fa = (uint32_t)lane;
+  for (uint32_t i = 0; i < found; ++i) {
+    const uint32_t s = readlane_u(shard, (int)i);
+    if (live && s == shard && i < fa) fa = i;
+  }
+  const uint32_t okey = live ? fa * 64u + (uint32_t)lane : kNoPos;
+  uint32_t g = 0;
+  for (uint32_t i = 0; i < found; ++i) {
+    const uint32_t k2 = readlane_u(okey, (int)i);
+    g += (k2 < okey) ? 1u : 0u;
+  }
+  if ((uint32_t)lane < a.P) {
+    a.probes[(size_t)q * a.P + lane] = live ? mylist : kNoPos;
+    a.gorder[(size_t)q * a.P + lane] = live ? g : kNoPos;
+    if (live && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist], 1u);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// grouping (counting sort of (query, probe) pairs by list)
+// ------------------------------------------------------------------------------------------
+// single block: exclusive scans of cnt[] and ceil(cnt/QG); stats[0] = Σ cnt*len, stats[1] = items
+__global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
+                                                          uint32_t nlists, uint32_t qg, uint32_t *seg_start,
+                                                          uint32_t *item_start, uint64_t *stats) {
+  __shared__ uint32_t s_seg[1024], s_item[1024];
+  __shared__ unsigned long long s_vec[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (nlists + 1023) / 1024;
+  const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
+  uint32_t seg = 0, item = 0;
+  unsigned long long vec = 0;
+  for (uint32_t l = beg; l < end; ++l) {
+    const uint32_t c = cnt[l];
+    seg += c;
+    item += (c + qg - 1) / qg;
+    vec += (unsigned long long)c * list_len[l];
+  }
+  s_seg[t] = seg; s_item[t] = item; s_vec[t] = vec;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t a = 0, b = 0;
+    unsigned long long c = 0;
+    if (t >= off) { a = s_seg[t - off]; b = s_item[t - off]; c = s_vec[t - off]; }
+    __syncthreads();
+    s_seg[t] += a; s_item[t] += b; s_vec[t] += c;
+    __syncthreads();
+  }
+  uint32_t rs = s_seg[t] - seg, ri = s_item[t] - item;
+  for (uint32_t l = beg; l < end; ++l) {
+    const uint32_t c = cnt[l];
+    seg_start[l] = rs; item_start[l] = ri;
+    rs += c; ri += (c + qg - 1) / qg;
+  }
+  if (t == 1023) {
+    seg_start[nlists] = s_seg[1023];
+    item_start[nlists] = s_item[1023];
+    stats[0] = s_vec[1023];
+    stats[1] = s_item[1023];
+  }
+}
+
+__global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, const uint32_t *seg_start,
+                                     uint32_t *cursor, uint32_t *pairs, uint32_t total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t l = probes[i];
+  if (l == kNoPos || list_len[l] == 0) return;
+  const uint32_t pos = atomicAdd(&cursor[l], 1u);
+  pairs[seg_start[l] + pos] = i;  // slot id = q*P + rank
+}
+
+// ------------------------------------------------------------------------------------------
+// final merge: P sorted runs per query -> top-k in the reference's stable candidate order
+// ------------------------------------------------------------------------------------------
+struct FinalMergeArgs {
+  const float *run_dist;
+  const uint32_t *run_pos;
+  uint32_t nq, P, K, k;           // K entries per run; k outputs per query
+  const uint32_t *probes, *gorder, *first_block;
+  const uint64_t *ext_ids;
+  float *D;
+  int64_t *I;
+  uint64_t *tie;                  // optional
+  uint64_t *slots;                // optional
+  uint32_t *counts;               // optional
+};
+
+__global__ void __launch_bounds__(kBlockThreads) final_merge_kernel(FinalMergeArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t q = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (q >= a.nq) return;
+  const size_t slot = (size_t)q * a.P + lane;
+  const size_t base = slot * a.K;
+  uint32_t head = 0, hp = kNoPos, g = kNoPos, list = kNoPos;
+  float hd = INFINITY;
+  if (lane < (int)a.P) {
+    list = a.probes[slot];
+    g = a.gorder[slot];
+    if (list != kNoPos) { hd = a.run_dist[base]; hp = a.run_pos[base]; }
+  }
+  uint32_t found = 0;
+  const uint32_t kk = a.k < a.P * a.K ? a.k : a.P * a.K;
+  for (uint32_t i = 0; i < kk; ++i) {
+    // (dist, shard-visit/probe order g, position): the stable sort of ivf_index.rs:265
+    const uint64_t key = (hp == kNoPos) ? ~0ull : (((uint64_t)__float_as_uint(hd) << 32) | g);
+    const uint64_t m = wave_min_u64(key);
+    if (m == ~0ull) break;
+    if (key == m) {
+      const size_t o = (size_t)q * a.k + i;
+      const uint64_t gslot = (uint64_t)a.first_block[list] * kWave + hp;
+      a.D[o] = hd;
+      a.I[o] = (int64_t)a.ext_ids[gslot];
+      if (a.tie) a.tie[o] = ((uint64_t)g << 32) | hp;
+      if (a.slots) a.slots[o] = gslot;
+      ++head;
+      if (head < a.K) { hd = a.run_dist[base + head]; hp = a.run_pos[base + head]; }
+      else hp = kNoPos;
+    }
+    ++found;
+  }
+  for (uint32_t i = found + lane; i < a.k; i += kWave) {  // lib.rs:179-187 padding
+    const size_t o = (size_t)q * a.k + i;
+    a.D[o] = INFINITY;
+    a.I[o] = -1;
+    if (a.tie) a.tie[o] = ~0ull;
+    if (a.slots) a.slots[o] = ~0ull;
+  }
+  if (a.counts && lane == 0) a.counts[q] = found;
+}
+
+// merge `parts` partial top-k lists per query (multi-GPU): key = (dist, tie)
+__global__ void __launch_bounds__(kBlockThreads) merge_partials_kernel(uint64_t nq, uint32_t k, uint32_t parts,
+                                                                      const float *Dp, const int64_t *Ip,
+                                                                      const uint64_t *Tp, float *D, int64_t *I) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint64_t q = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  // lane = part (parts <= 64); each part's list is sorted by (dist, tie) already
+  const size_t base = ((size_t)lane * nq + q) * k;
+  uint32_t head = 0;
+  bool live = lane < (int)parts;
+  float hd = INFINITY;
+  uint64_t ht = ~0ull;
+  int64_t hi = -1;
+  if (live) { hd = Dp[base]; ht = Tp[base]; hi = Ip[base]; live = hi >= 0; }
+  uint32_t found = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    // two-level key: distance bits first, then the 64-bit tie key
+    const uint64_t kd = live ? (uint64_t)__float_as_uint(hd) : ~0ull;
+    const uint64_t md = wave_min_u64(kd);
+    if (md == ~0ull) break;
+    const uint64_t kt = (live && kd == md) ? ht : ~0ull;
+    const uint64_t mt = wave_min_u64(kt);
+    if (live && kd == md && kt == mt) {
+      D[q * k + i] = hd;
+      I[q * k + i] = hi;
+      ++head;
+      if (head < k) { hd = Dp[base + head]; ht = Tp[base + head]; hi = Ip[base + head]; live = hi >= 0; }
+      else live = false;
+    }
+    ++found;
+  }
+  for (uint32_t i = found + lane; i < k; i += kWave) { D[q * k + i] = INFINITY; I[q * k + i] = -1; }
+}
+
+// ------------------------------------------------------------------------------------------
+// repack: AoS records (or row-major rows) -> lane-interleaved blocks (+ external ids)
+// ------------------------------------------------------------------------------------------
+struct RepackArgs {
+  const uint8_t *src;           // device image of a shard file / row-major matrix
+  const uint64_t *blk_src;      // [nb] byte offset of the first record of each destination block
+  const uint32_t *blk_nv;       // [nb] valid vectors in the block (1..64)
+  const uint32_t *blk_dst;      // [nb] destination block index
+  uint32_t nb, dim, dq;
+  uint32_t stride;              // bytes between consecutive records
+  uint32_t vec_off;             // byte offset of the f32 payload inside a record
+  int32_t id_off;               // byte offset of the u64 external id, or -1
+  float *blocks;
+  uint64_t *ext_ids;            // may be null
+};
+
+__global__ void __launch_bounds__(kBlockThreads) repack_kernel(RepackArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (b >= a.nb) return;
+  const uint32_t nv = a.blk_nv[b], dst = a.blk_dst[b];
+  const uint8_t *rec = a.src + a.blk_src[b] + (size_t)lane * a.stride;
+  const bool valid = (uint32_t)lane < nv;
+  const float *v = reinterpret_cast<const float *>(rec + a.vec_off);
+  float4 *out = reinterpret_cast<float4 *>(a.blocks) + ((size_t)dst * a.dq) * kWave + lane;
+  for (uint32_t qd = 0; qd < a.dq; ++qd) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t e = qd * 4;
+    if (valid) {
+      if (e + 0 < a.dim) x.x = v[e + 0];
+      if (e + 1 < a.dim) x.y = v[e + 1];
+      if (e + 2 < a.dim) x.z = v[e + 2];
+      if (e + 3 < a.dim) x.w = v[e + 3];
+    }
+    out[(size_t)qd * kWave] = x;
+  }
+  if (a.ext_ids) {
+    uint64_t id = ~0ull;
+    if (valid && a.id_off >= 0) id = *reinterpret_cast<const uint64_t *>(rec + a.id_off);
+    a.ext_ids[(size_t)dst * kWave + lane] = id;
+  }
+}
+
+// gather result vectors (include_vectors, api.rs:213-217) back to row-major
+__global__ void gather_vectors_kernel(const float *blocks, uint32_t dq, uint32_t dim, const uint64_t *slots,
+                                      uint64_t nres, float *V) {
+  const uint64_t r = blockIdx.x;
+  if (r >= nres) return;
+  const uint64_t s = slots[r];
+  for (uint32_t e = threadIdx.x; e < dim; e += blockDim.x) {
+    float val = 0.0f;
+    if (s != ~0ull) {
+      const uint64_t blk = s / kWave, ln = s % kWave;
+      val = blocks[((blk * dq + e / 4) * kWave + ln) * 4 + (e & 3)];
+    }
+    V[r * dim + e] = val;
+  }
+}
+
+// rows of a row-major matrix -> lane-interleaved blocks (one lane per destination slot)
+__global__ void __launch_bounds__(kBlockThreads) repack_rows_kernel(const float *src, uint32_t dim, uint32_t dq,
+                                                                   const uint32_t *row_of_slot, uint64_t nslots,
+                                                                   const uint64_t *id_of_row, float *blocks,
+                                                                   uint64_t *ids_out) {
+  const uint64_t s = (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (s >= nslots) return;
+  const uint32_t row = row_of_slot[s];
+  const bool valid = row != kNoPos;
+  const float *v = src + (size_t)row * dim;
+  float4 *out = reinterpret_cast<float4 *>(blocks) + ((s / kWave) * dq) * kWave + (s % kWave);
+  for (uint32_t qd = 0; qd < dq; ++qd) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t e = qd * 4;
+    if (valid) {
+      if (e + 0 < dim) x.x = v[e + 0];
+      if (e + 1 < dim) x.y = v[e + 1];
+      if (e + 2 < dim) x.z = v[e + 2];
+      if (e + 3 < dim) x.w = v[e + 3];
+    }
+    out[(size_t)qd * kWave] = x;
+  }
+  if (ids_out) ids_out[s] = valid ? (id_of_row ? id_of_row[row] : (uint64_t)row) : ~0ull;
+}
+
+// plain pairwise distances in either order (vi_l2sq_pairs)
+__global__ void l2sq_pairs_kernel(const float *a, const float *b, uint64_t n, uint32_t d, int order, float *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *p = a + i * d, *c = b + i * d;
+  if (order == VI_ORDER_SCALAR) {
+    float acc = 0.0f;
+    for (uint32_t j = 0; j < d; ++j) sq_add(acc, p[j], c[j]);
+    out[i] = acc;
+    return;
+  }
+  float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, tail = 0.0f;
+  uint32_t j = 0;
+  for (; j + 8 <= d; j += 8)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) sq_add(a8[l], p[j + l], c[j + l]);
+  for (; j + 4 <= d; j += 4)
+#pragma unroll
+    for (int l = 0; l < 4; ++l) sq_add(a4[l], p[j + l], c[j + l]);
+  for (; j < d; ++j) sq_add(tail, p[j], c[j]);
+  const float lo = ((a8[0] + a8[1]) + a8[2]) + a8[3];
+  const float hi = ((a8[4] + a8[5]) + a8[6]) + a8[7];
+  const float r4 = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+  out[i] = ((lo + hi) + r4) + tail;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------
+template <int QG, int ORDER, bool COARSE>
+vi_status launch_scan_t(const ScanArgs &a, uint32_t nitems_upper, hipStream_t st) {
+  if (nitems_upper == 0) return VI_OK;
+  const uint32_t grid = (nitems_upper + kWavesPerBlock - 1) / kWavesPerBlock;
+  const size_t smem = (size_t)kWavesPerBlock * QG * a.dq * sizeof(float4);
+  if (smem > 64 * 1024)
+    VI_HIP(hipFuncSetAttribute((const void *)scan_kernel<QG, ORDER, COARSE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((scan_kernel<QG, ORDER, COARSE>), dim3(grid), dim3(kBlockThreads), smem, st, a);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
+}  // namespace
+
+// Chosen so that QG*dq float4 per wave stays within the 160 KiB LDS of a CU at 4 waves/block.
+int pick_qg(uint32_t dq, double avg_queries_per_unit, int order) {
+  const int cap = order == VI_ORDER_LANES ? 4 : 8;
+  int qg = 1;
+  if (avg_queries_per_unit >= 3.0) qg = 4;
+  if (avg_queries_per_unit >= 6.0) qg = 8;
+  qg = std::min(qg, cap);
+  while (qg > 1 && (size_t)kWavesPerBlock * qg * dq * sizeof(float4) > 96 * 1024) qg = (qg == 8) ? 4 : 1;
+  return qg;
+}
+
+vi_status launch_scan(const ScanArgs &a, int qg, int order, bool coarse, uint32_t nitems_upper, hipStream_t st) {
+#define VI_SCAN_CASE(QGV)                                                                               \
+  if (qg == QGV) {                                                                                      \
+    if (order == VI_ORDER_SCALAR)                                                                       \
+      return coarse ? launch_scan_t<QGV, VI_ORDER_SCALAR, true>(a, nitems_upper, st)                    \
+                    : launch_scan_t<QGV, VI_ORDER_SCALAR, false>(a, nitems_upper, st);                  \
+    return coarse ? launch_scan_t<(QGV > 4 ? 4 : QGV), VI_ORDER_LANES, true>(a, nitems_upper, st)      \
+                  : launch_scan_t<(QGV > 4 ? 4 : QGV), VI_ORDER_LANES, false>(a, nitems_upper, st);     \
+  }
+  VI_SCAN_CASE(1)
+  VI_SCAN_CASE(4)
+  VI_SCAN_CASE(8)
+#undef VI_SCAN_CASE
+  return fail(VI_ERR_OTHER, "unsupported query group %d", qg);
+}
+
+uint32_t coarse_splits(uint64_t nq, int qg, uint32_t nblk, uint32_t *bps) {
+  const uint32_t nqg = (uint32_t)((nq + qg - 1) / qg);
+  uint32_t S = std::max<uint32_t>(1, std::min<uint32_t>({(uint32_t)kMaxSelect, nblk, (4096 + nqg - 1) / nqg}));
+  *bps = (std::max<uint32_t>(nblk, 1) + S - 1) / S;
+  return std::max<uint32_t>(1, (nblk + *bps - 1) / *bps);
+}
+
+vi_status launch_repack_rows(const float *src, uint32_t dim, uint32_t dq, const uint32_t *row_of_slot,
+                             uint64_t nslots, const uint64_t *id_of_row, float *blocks, uint64_t *ids_out,
+                             hipStream_t st) {
+  if (nslots == 0) return VI_OK;
+  hipLaunchKernelGGL(repack_rows_kernel, dim3((uint32_t)((nslots + kBlockThreads - 1) / kBlockThreads)),
+                     dim3(kBlockThreads), 0, st, src, dim, dq, row_of_slot, nslots, id_of_row, blocks, ids_out);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
+DeviceIndex::~DeviceIndex() {
+  for (auto &e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// upload
+// ------------------------------------------------------------------------------------------
+static vi_status repack_upload(const uint8_t *host_src, size_t src_bytes, const std::vector<uint64_t> &blk_src,
+                               const std::vector<uint32_t> &blk_nv, const std::vector<uint32_t> &blk_dst,
+                               uint32_t dim, uint32_t dq, uint32_t stride, uint32_t vec_off, int32_t id_off,
+                               float *blocks, uint64_t *ext_ids, hipStream_t st) {
+  const uint32_t nb = (uint32_t)blk_src.size();
+  if (nb == 0) return VI_OK;
+  DevBuf<uint8_t> img;
+  DevBuf<uint64_t> dsrc;
+  DevBuf<uint32_t> dnv, ddst;
+  VI_TRY(img.reserve(src_bytes + 16));
+  VI_TRY(dsrc.reserve(nb));
+  VI_TRY(dnv.reserve(nb));
+  VI_TRY(ddst.reserve(nb));
+  VI_HIP(hipMemcpyAsync(img.p, host_src, src_bytes, hipMemcpyHostToDevice, st));
+  VI_HIP(hipMemcpyAsync(dsrc.p, blk_src.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  VI_HIP(hipMemcpyAsync(dnv.p, blk_nv.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  VI_HIP(hipMemcpyAsync(ddst.p, blk_dst.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  RepackArgs a{img.p, dsrc.p, dnv.p, ddst.p, nb, dim, dq, stride, vec_off, id_off, blocks, ext_ids};
+  hipLaunchKernelGGL(repack_kernel, dim3((nb + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads), 0, st, a);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipStreamSynchronize(st));  // img is freed on return
+  return VI_OK;
+}
+
+static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists);
+
+vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir, int device, int rank, int world,
+                            DeviceIndex *ix) {
+  VI_TRY(init_device_index(ix, device, meta.dimension, meta.k()));
+  const uint32_t dim = ix->dim, dq = ix->dq;
+  const uint64_t k = ix->nlists;
+
+  // ---- centroid table ----
+  {
+    const uint64_t nb = (k + kWave - 1) / kWave;
+    ix->centroids.dq = dq;
+    ix->centroids.nblocks = nb;
+    VI_TRY(ix->centroids.blocks.reserve(std::max<uint64_t>(1, nb) * dq * kWave * 4));
+    std::vector<uint64_t> src(nb);
+    std::vector<uint32_t> nv(nb), dst(nb);
+    for (uint64_t b = 0; b < nb; ++b) {
+      src[b] = b * kWave * (uint64_t)dim * 4;
+      nv[b] = (uint32_t)std::min<uint64_t>(kWave, k - b * kWave);
+      dst[b] = (uint32_t)b;
+    }
+    VI_TRY(repack_upload((const uint8_t *)meta.centroids.data(), meta.centroids.size() * 4, src, nv, dst, dim, dq,
+                         dim * 4, 0, -1, ix->centroids.blocks.p, nullptr, ix->stream));
+  }
+
+  // ---- lists: open the shard files this rank owns ----
+  uint64_t nshards = 0;
+  for (uint64_t c = 0; c < k; ++c) nshards = std::max(nshards, meta.c2s[c] + 1);
+  ix->nshards = nshards;
+  std::vector<uint32_t> h_first(k, 0), h_len(k, 0), h_shard(k, 0);
+  for (uint64_t c = 0; c < k; ++c) h_shard[c] = (uint32_t)meta.c2s[c];
+  std::vector<std::unique_ptr<ShardFile>> files(nshards);
+  const bool part = world > 1;
+  uint64_t total_blocks = 0, total_vec = 0;
+  for (uint64_t s = 0; s < nshards; ++s) {
+    if (part && (int)(s % (uint64_t)world) != rank) continue;
+    auto f = std::make_unique<ShardFile>();
+    // a missing/corrupt shard is skipped, as search does (`if let Ok`, ivf_index.rs:253-254)
+    if (f->open(shards_dir, s) != VI_OK || f->dim() != dim) continue;
+    files[s] = std::move(f);
+  }
+  for (uint64_t c = 0; c < k; ++c) {
+    const uint64_t s = meta.c2s[c];
+    if (s >= nshards || !files[s]) continue;
+    const ShardListView *lv = files[s]->find(c);
+    if (!lv) { files[s].reset(); continue; }  // NotFound fails the whole shard read (shards.rs:257-265)
+  }
+  for (uint64_t c = 0; c < k; ++c) {
+    const uint64_t s = meta.c2s[c];
+    if (s >= nshards || !files[s]) continue;
+    const ShardListView *lv = files[s]->find(c);
+    h_first[c] = (uint32_t)total_blocks;
+    h_len[c] = lv->num_vectors;
+    total_blocks += (lv->num_vectors + kWave - 1) / kWave;
+    total_vec += lv->num_vectors;
+  }
+  if (total_blocks >= 0xFFFFFFFFull / kWave) return fail(VI_ERR_OTHER, "index too large for 32-bit slot ids");
+  ix->nvec_resident = total_vec;
+  ix->lists.dq = dq;
+  ix->lists.nblocks = total_blocks;
+  VI_TRY(ix->lists.blocks.reserve(std::max<uint64_t>(1, total_blocks) * dq * kWave * 4));
+  VI_TRY(ix->ext_ids.reserve(std::max<uint64_t>(1, total_blocks) * kWave));
+  const uint32_t stride = (uint32_t)record_stride(dim);
+  for (uint64_t s = 0; s < nshards; ++s) {
+    if (!files[s]) continue;
+    const ShardFile &f = *files[s];
+    std::vector<uint64_t> src;
+    std::vector<uint32_t> nv, dst;
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    for (uint32_t i = 0; i < f.num_lists(); ++i) {
+      const ShardListView &lv = f.list(i);
+      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0) continue;
+      if (!lo || lv.records < lo) lo = lv.records;
+      const uint8_t *end = lv.records + (uint64_t)lv.num_vectors * stride;
+      if (!hi || end > hi) hi = end;
+    }
+    if (!lo) continue;
+    for (uint32_t i = 0; i < f.num_lists(); ++i) {
+      const ShardListView &lv = f.list(i);
+      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0) continue;
+      const uint32_t nb = (lv.num_vectors + kWave - 1) / kWave;
+      for (uint32_t b = 0; b < nb; ++b) {
+        src.push_back((uint64_t)(lv.records - lo) + (uint64_t)b * kWave * stride);
+        nv.push_back(std::min<uint32_t>(kWave, lv.num_vectors - b * kWave));
+        dst.push_back(h_first[lv.centroid_id] + b);
+      }
+    }
+    VI_TRY(repack_upload(lo, (size_t)(hi - lo), src, nv, dst, dim, dq, stride, (uint32_t)kVectorMetaBytes, 8,
+                         ix->lists.blocks.p, ix->ext_ids.p, ix->stream));
+  }
+  VI_TRY(ix->list_first_block.reserve(std::max<uint64_t>(1, k)));
+  VI_TRY(ix->list_len.reserve(std::max<uint64_t>(1, k)));
+  VI_TRY(ix->list_shard.reserve(std::max<uint64_t>(1, k)));
+  if (k) {
+    VI_HIP(hipMemcpy(ix->list_first_block.p, h_first.data(), k * 4, hipMemcpyHostToDevice));
+    VI_HIP(hipMemcpy(ix->list_len.p, h_len.data(), k * 4, hipMemcpyHostToDevice));
+    VI_HIP(hipMemcpy(ix->list_shard.p, h_shard.data(), k * 4, hipMemcpyHostToDevice));
+  }
+  return VI_OK;
+}
+
+static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(VI_ERR_DEVICE, "no HIP device visible: libvi_amd never falls back to the CPU");
+  if (device < 0 || device >= ndev) return fail(VI_ERR_DEVICE, "device %d out of range (%d visible)", device, ndev);
+  VI_HIP(hipSetDevice(device));
+  ix->device = device;
+  ix->dim = dim;
+  ix->dq = (dim + 3) / 4;
+  ix->nlists = nlists;
+  if (!ix->stream) VI_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  for (auto &e : ix->ev)
+    if (!e) VI_HIP(hipEventCreate(&e));
+  return VI_OK;
+}
+
+vi_status device_index_from_rows(int device, int order, uint32_t dim, const float *table_dev, uint64_t ntable,
+                                 const float *rows_dev, const std::vector<uint64_t> &list_off,
+                                 const std::vector<uint32_t> &member_rows, const uint64_t *ids_dev,
+                                 const std::vector<uint32_t> *list_shard, DeviceIndex *ix) {
+  const uint64_t nlists = list_off.size() - 1;
+  if (nlists != ntable) return fail(VI_ERR_INVALID_INPUT, "table rows must equal list count");
+  VI_TRY(init_device_index(ix, device, dim, nlists));
+  ix->order = order;
+  const uint32_t dq = ix->dq;
+  hipStream_t st = ix->stream;
+  // coarse table
+  {
+    const uint64_t nb = (ntable + kWave - 1) / kWave;
+    ix->centroids.dq = dq;
+    ix->centroids.nblocks = nb;
+    VI_TRY(ix->centroids.blocks.reserve(std::max<uint64_t>(1, nb) * dq * kWave * 4));
+    std::vector<uint32_t> ros(nb * kWave, kNoPos);
+    for (uint64_t i = 0; i < ntable; ++i) ros[i] = (uint32_t)i;
+    DevBuf<uint32_t> dros;
+    VI_TRY(dros.reserve(ros.size()));
+    VI_HIP(hipMemcpyAsync(dros.p, ros.data(), ros.size() * 4, hipMemcpyHostToDevice, st));
+    VI_TRY(launch_repack_rows(table_dev, dim, dq, dros.p, ros.size(), nullptr, ix->centroids.blocks.p, nullptr, st));
+    VI_HIP(hipStreamSynchronize(st));
+  }
+  std::vector<uint32_t> h_first(nlists, 0), h_len(nlists, 0), h_shard(nlists, 0);
+  uint64_t total_blocks = 0;
+  for (uint64_t l = 0; l < nlists; ++l) {
+    const uint64_t len = list_off[l + 1] - list_off[l];
+    h_first[l] = (uint32_t)total_blocks;
+    h_len[l] = (uint32_t)len;
+    h_shard[l] = list_shard ? (*list_shard)[l] : (uint32_t)l;
+    total_blocks += (len + kWave - 1) / kWave;
+  }
+  if (total_blocks >= 0xFFFFFFFFull / kWave) return fail(VI_ERR_OTHER, "index too large for 32-bit slot ids");
+  ix->nvec_resident = member_rows.size();
+  ix->nshards = 0;
+  for (uint64_t l = 0; l < nlists; ++l) ix->nshards = std::max<uint64_t>(ix->nshards, (uint64_t)h_shard[l] + 1);
+  ix->lists.dq = dq;
+  ix->lists.nblocks = total_blocks;
+  VI_TRY(ix->lists.blocks.reserve(std::max<uint64_t>(1, total_blocks) * dq * kWave * 4));
+  VI_TRY(ix->ext_ids.reserve(std::max<uint64_t>(1, total_blocks) * kWave));
+  {
+    std::vector<uint32_t> ros(total_blocks * kWave, kNoPos);
+    for (uint64_t l = 0; l < nlists; ++l)
+      for (uint64_t e = list_off[l]; e < list_off[l + 1]; ++e)
+        ros[(uint64_t)h_first[l] * kWave + (e - list_off[l])] = member_rows[e];
+    DevBuf<uint32_t> dros;
+    VI_TRY(dros.reserve(ros.size()));
+    if (!ros.empty()) VI_HIP(hipMemcpyAsync(dros.p, ros.data(), ros.size() * 4, hipMemcpyHostToDevice, st));
+    VI_TRY(launch_repack_rows(rows_dev, dim, dq, dros.p, ros.size(), ids_dev, ix->lists.blocks.p, ix->ext_ids.p, st));
+    VI_HIP(hipStreamSynchronize(st));
+  }
+  VI_TRY(ix->list_first_block.reserve(std::max<uint64_t>(1, nlists)));
+  VI_TRY(ix->list_len.reserve(std::max<uint64_t>(1, nlists)));
+  VI_TRY(ix->list_shard.reserve(std::max<uint64_t>(1, nlists)));
+  if (nlists) {
+    VI_HIP(hipMemcpy(ix->list_first_block.p, h_first.data(), nlists * 4, hipMemcpyHostToDevice));
+    VI_HIP(hipMemcpy(ix->list_len.p, h_len.data(), nlists * 4, hipMemcpyHostToDevice));
+    VI_HIP(hipMemcpy(ix->list_shard.p, h_shard.data(), nlists * 4, hipMemcpyHostToDevice));
+  }
+  return VI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// search pipeline (fast path: n_probe_eff <= 64 and k <= 64)
+// ------------------------------------------------------------------------------------------
+vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
+  std::lock_guard<std::mutex> lock(ix.mu);
+  VI_HIP(hipSetDevice(ix.device));
+  hipStream_t st = ix.stream;
+  SearchWorkspace &ws = ix.ws;
+  const uint64_t nq = io.nq, k = io.k;
+  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint64_t nlists = ix.nlists;
+  if (nq == 0) return VI_OK;
+  if (nq * std::max<uint64_t>(k, 64) > 0x7FFFFFFFull) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
+  const uint32_t P = (uint32_t)std::min<uint64_t>(io.n_probe, nlists);  // take(n_probe) (ivf_index.rs:216-220)
+  const uint32_t K = (uint32_t)std::min<uint64_t>(k, kMaxSelect);
+  if (P > kMaxSelect || k > kMaxSelect)
+    return fail(VI_ERR_OTHER, "k=%llu / n_probe=%u beyond the wave-select fast path (generic path not built yet)",
+                (unsigned long long)k, P);
+
+  // ---- outputs / queries on device ----
+  const float *Qd = io.queries;
+  float *Dd = io.D;
+  int64_t *Id = io.I;
+  uint64_t *Td = io.tie;
+  if (!io.on_device) {
+    VI_TRY(ws.q.reserve(nq * dim));
+    VI_TRY(ws.D.reserve(nq * k));
+    VI_TRY(ws.I.reserve(nq * k));
+    VI_HIP(hipMemcpyAsync(ws.q.p, io.queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, st));
+    Qd = ws.q.p; Dd = ws.D.p; Id = ws.I.p; Td = nullptr;
+  }
+  VI_TRY(ws.counts.reserve(nq));
+  VI_TRY(ws.stats.reserve(8));
+  uint64_t *slots = nullptr;
+  if (io.V) { VI_TRY(ws.slots.reserve(nq * k)); slots = ws.slots.p; }
+
+  vi_search_stats &stt = ix.stats;
+  stt = vi_search_stats{};
+  stt.nq = nq; stt.k = k; stt.n_probe_eff = P; stt.coarse_candidates = nq * nlists;
+
+  if (P == 0 || nlists == 0) {  // empty index: every query has zero results
+    std::vector<float> hD(nq * k, INFINITY);
+    std::vector<int64_t> hI(nq * k, -1);
+    if (io.on_device) {
+      VI_HIP(hipMemcpy(io.D, hD.data(), hD.size() * 4, hipMemcpyHostToDevice));
+      VI_HIP(hipMemcpy(io.I, hI.data(), hI.size() * 8, hipMemcpyHostToDevice));
+    } else {
+      std::memcpy(io.D, hD.data(), hD.size() * 4);
+      std::memcpy(io.I, hI.data(), hI.size() * 8);
+      if (io.counts) std::memset(io.counts, 0, nq * 8);
+      if (io.V) std::memset(io.V, 0, nq * k * dim * 4);
+    }
+    return VI_OK;
+  }
+
+  const bool timing = ix.timing;
+  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+
+  // ---- 1. coarse scan over the centroid table ----
+  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
+  const int qg_c = pick_qg(dq, (double)nq, ix.order);
+  const uint32_t nqg = (uint32_t)((nq + qg_c - 1) / qg_c);
+  uint32_t bps = 0;
+  const uint32_t S = coarse_splits(nq, qg_c, nblk_c, &bps);
+  VI_TRY(ws.crun_dist.reserve(nq * S * P));
+  VI_TRY(ws.crun_pos.reserve(nq * S * P));
+  {
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
+    a.K = P; a.run_dist = ws.crun_dist.p; a.run_pos = ws.crun_pos.p;
+    a.nvec = (uint32_t)nlists; a.S = S; a.bps = bps;
+    VI_TRY(launch_scan(a, qg_c, ix.order, true, nqg * S, st));
+  }
+  // ---- 2. merge -> probes, shard order, histogram ----
+  VI_TRY(ws.probes.reserve(nq * P));
+  VI_TRY(ws.gorder.reserve(nq * P));
+  VI_TRY(ws.cnt.reserve(2 * nlists));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  {
+    CoarseMergeArgs a{ws.crun_dist.p, ws.crun_pos.p, (uint32_t)nq, S, P, ix.list_shard.p, ix.list_len.p,
+                      ws.probes.p, ws.gorder.p, ws.cnt.p};
+    hipLaunchKernelGGL(coarse_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                       dim3(kBlockThreads), 0, st, a);
+    VI_HIP(hipGetLastError());
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
+  // ---- 3. group (query,probe) pairs by list ----
+  const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
+  const int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
+  VI_TRY(ws.seg_start.reserve(nlists + 1));
+  VI_TRY(ws.item_start.reserve(nlists + 1));
+  VI_TRY(ws.pairs.reserve(nq * P));
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
+                     (uint32_t)qg_l, ws.seg_start.p, ws.item_start.p, ws.stats.p);
+  VI_HIP(hipGetLastError());
+  {
+    const uint32_t total = (uint32_t)(nq * P);
+    hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
+                       ix.list_len.p, ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
+    VI_HIP(hipGetLastError());
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
+  // ---- 4. list scan ----
+  VI_TRY(ws.run_dist.reserve(nq * P * K));
+  VI_TRY(ws.run_pos.reserve(nq * P * K));
+  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
+  {
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
+    a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
+    a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
+    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P;
+    const uint64_t upper = (nq * P + qg_l - 1) / qg_l + std::min<uint64_t>(nlists, nq * P);
+    VI_TRY(launch_scan(a, qg_l, ix.order, false, (uint32_t)upper, st));
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
+  // ---- 5. final merge ----
+  {
+    FinalMergeArgs a{ws.run_dist.p, ws.run_pos.p, (uint32_t)nq, P, K, (uint32_t)k, ws.probes.p, ws.gorder.p,
+                     ix.list_first_block.p, ix.ext_ids.p, Dd, Id, Td, slots, ws.counts.p};
+    hipLaunchKernelGGL(final_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                       dim3(kBlockThreads), 0, st, a);
+    VI_HIP(hipGetLastError());
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+
+  // ---- results ----
+  if (!io.on_device) {
+    VI_HIP(hipMemcpyAsync(io.D, Dd, nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    VI_HIP(hipMemcpyAsync(io.I, Id, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (io.V) {
+      VI_TRY(ws.V.reserve(nq * k * dim));
+      hipLaunchKernelGGL(gather_vectors_kernel, dim3((uint32_t)(nq * k)), dim3(64), 0, st, ix.lists.blocks.p, dq, dim,
+                         slots, nq * k, ws.V.p);
+      VI_HIP(hipGetLastError());
+      VI_HIP(hipMemcpyAsync(io.V, ws.V.p, nq * k * dim * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    if (io.counts) {
+      std::vector<uint32_t> c32(nq);
+      VI_HIP(hipMemcpyAsync(c32.data(), ws.counts.p, nq * 4, hipMemcpyDeviceToHost, st));
+      VI_HIP(hipStreamSynchronize(st));
+      for (uint64_t i = 0; i < nq; ++i) io.counts[i] = c32[i];
+    }
+  }
+  uint64_t hstats[2] = {0, 0};
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
+  stt.scanned_vectors = hstats[0];
+  stt.scan_items = hstats[1];
+  if (timing) {
+    (void)hipEventElapsedTime(&stt.ms_coarse, ix.ev[0], ix.ev[1]);
+    (void)hipEventElapsedTime(&stt.ms_group, ix.ev[1], ix.ev[2]);
+    (void)hipEventElapsedTime(&stt.ms_scan, ix.ev[2], ix.ev[3]);
+    (void)hipEventElapsedTime(&stt.ms_merge, ix.ev[3], ix.ev[4]);
+    (void)hipEventElapsedTime(&stt.ms_total, ix.ev[0], ix.ev[4]);
+  }
+  return VI_OK;
+}
+
+vi_status merge_partials_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const float *D_parts,
+                                const int64_t *I_parts, const uint64_t *tie_parts, float *D_out, int64_t *I_out) {
+  if (parts == 0 || parts > kWave) return fail(VI_ERR_INVALID_INPUT, "parts must be 1..64");
+  if (nq == 0 || k == 0) return VI_OK;
+  VI_HIP(hipSetDevice(device));
+  hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                     dim3(kBlockThreads), 0, 0, nq, (uint32_t)k, parts, D_parts, I_parts, tie_parts, D_out, I_out);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipStreamSynchronize(0));
+  return VI_OK;
+}
+
+vi_status l2sq_pairs_device(const float *a, const float *b, uint64_t n, uint32_t d, int order, float *out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VI_ERR_DEVICE, "no HIP device visible");
+  if (n == 0) return VI_OK;
+  DevBuf<float> da, db, dout;
+  VI_TRY(da.reserve(n * d));
+  VI_TRY(db.reserve(n * d));
+  VI_TRY(dout.reserve(n));
+  VI_HIP(hipMemcpy(da.p, a, n * d * 4, hipMemcpyHostToDevice));
+  VI_HIP(hipMemcpy(db.p, b, n * d * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(l2sq_pairs_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, da.p, db.p, n, d, order,
+                     dout.p);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+  return VI_OK;
+}
+
+}  // namespace vi
