@@ -1057,6 +1057,59 @@ int orc_index_search(const orc_index *ix, const float *q, uint64_t k, uint64_t n
   return rc;
 }
 
+/* Multi-GPU protocol checker: the search of rank `rank` of `world` (lists of shards
+ * s % world == rank only), with the GLOBAL candidate-order key of every hit:
+ * tie = (rank of the probe in the reference candidate order << 32) | position in list.
+ * Merging the per-rank outputs by (dist, tie) must reproduce orc_index_search. */
+int orc_index_search_partial(const orc_index *ix, const float *q, uint64_t k, uint64_t n_probe,
+                             uint32_t rank, uint32_t world, uint64_t *ids_out, float *dist_out,
+                             uint64_t *tie_out, uint64_t *count) {
+  if (k == 0 || n_probe == 0) return ORC_INVALID_INPUT;
+  size_t d = ix->dim;
+  dist_idx *cd = (dist_idx *)malloc(sizeof(dist_idx) * (ix->k + 1));
+  int rc = probe_lists(ix, q, n_probe, cd);
+  if (rc != ORC_OK) { free(cd); return rc; }
+  uint64_t np = n_probe < ix->k ? n_probe : ix->k;
+  uint64_t *shard_order = (uint64_t *)malloc(sizeof(uint64_t) * (np + 1));
+  uint64_t ns = 0;
+  for (uint64_t i = 0; i < np; ++i) {
+    uint64_t s = ix->c2s[cd[i].idx];
+    int seen = 0;
+    for (uint64_t j = 0; j < ns; ++j) if (shard_order[j] == s) { seen = 1; break; }
+    if (!seen) shard_order[ns++] = s;
+  }
+  size_t total = 0;
+  for (uint64_t i = 0; i < np; ++i) total += ix->list_len[cd[i].idx];
+  cand *cs = (cand *)malloc(sizeof(cand) * (total + 1));
+  uint64_t *ties = (uint64_t *)malloc(sizeof(uint64_t) * (total + 1));
+  size_t nc = 0;
+  uint64_t g = 0;
+  for (uint64_t si = 0; si < ns; ++si)
+    for (uint64_t i = 0; i < np; ++i) {
+      uint64_t c = cd[i].idx;
+      if (ix->c2s[c] != shard_order[si]) continue;
+      uint64_t my_g = g++;
+      if (world > 1 && (ix->c2s[c] % world) != rank) continue;
+      if (!ix->list_ok[c]) continue;
+      for (uint64_t v = 0; v < ix->list_len[c]; ++v) {
+        cs[nc].dist = orc_l2sq_scalar(q, ix->list_vec[c] + v * d, d);
+        cs[nc].order = (uint32_t)nc; cs[nc].list = c; cs[nc].pos = v;
+        ties[nc] = (my_g << 32) | v;
+        nc++;
+      }
+    }
+  qsort(cs, nc, sizeof(cand), cmp_cand);
+  uint64_t m = k < nc ? k : nc;
+  for (uint64_t i = 0; i < m; ++i) {
+    ids_out[i] = ix->list_meta[cs[i].list][3 * cs[i].pos + 1];
+    dist_out[i] = cs[i].dist;
+    tie_out[i] = ties[cs[i].order];
+  }
+  *count = m;
+  free(cd); free(shard_order); free(cs); free(ties);
+  return ORC_OK;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -159,6 +159,10 @@ int orc_index_search_batch(const orc_index *ix, const float *Q, uint64_t nq, uin
 /* coarse step only (ivf_index.rs:205-220): probe list for one query */
 int orc_index_probe(const orc_index *ix, const float *q, uint64_t n_probe,
                     uint64_t *probes_out, uint64_t *count);
+/* per-rank partial search with global tie keys (multi-GPU protocol checker) */
+int orc_index_search_partial(const orc_index *ix, const float *q, uint64_t k, uint64_t n_probe,
+                             uint32_t rank, uint32_t world, uint64_t *ids_out, float *dist_out,
+                             uint64_t *tie_out, uint64_t *count);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

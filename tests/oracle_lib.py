@@ -19,6 +19,24 @@ u64, u32, i64, f32 = C.c_uint64, C.c_uint32, C.c_int64, C.c_float
 P = C.POINTER
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (the GPU box
+    exposes every host core to nproc but gives the job a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+# OpenMP would otherwise start one spinning thread per visible host core
+os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def build_oracle(force=False):
     src = os.path.join(_ORACLE_DIR, "vi_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
@@ -77,6 +95,7 @@ def lib():
         "orc_index_search": (C.c_int, [vp, vp, u64, u64, vp, vp, vp, P(u64)]),
         "orc_index_search_batch": (C.c_int, [vp, vp, u64, u64, u64, C.c_int, vp, vp]),
         "orc_index_probe": (C.c_int, [vp, vp, u64, vp, P(u64)]),
+        "orc_index_search_partial": (C.c_int, [vp, vp, u64, u64, u32, u32, vp, vp, vp, P(u64)]),
         "orc_max_threads": (C.c_int, []),
     }
     for name, (res, args) in sigs.items():
@@ -284,6 +303,25 @@ class OracleIndex:
         I = np.zeros((nq, k), dtype=np.int64)
         rc = lib().orc_index_search_batch(self.h, _p(Q), nq, k, n_probe, threads, _p(D), _p(I))
         return rc, D, I
+
+    def search_partial_batch(self, Q, k, n_probe, rank, world):
+        """per-rank (D, I, tie) padded with +inf / -1 / 2^64-1 (multi-GPU protocol checker)"""
+        Q = f32c(Q)
+        nq = Q.shape[0]
+        D = np.full((nq, k), np.inf, dtype=np.float32)
+        I = np.full((nq, k), -1, dtype=np.int64)
+        T = np.full((nq, k), np.iinfo(np.uint64).max, dtype=np.uint64)
+        ids = np.zeros(k, dtype=np.uint64)
+        ds = np.zeros(k, dtype=np.float32)
+        ts = np.zeros(k, dtype=np.uint64)
+        for i in range(nq):
+            cnt = u64(0)
+            rc = lib().orc_index_search_partial(self.h, _p(Q[i]), k, n_probe, rank, world, _p(ids), _p(ds), _p(ts),
+                                                C.byref(cnt))
+            assert rc == ORC_OK
+            c = cnt.value
+            D[i, :c], I[i, :c], T[i, :c] = ds[:c], ids[:c].astype(np.int64), ts[:c]
+        return D, I, T
 
     def probe(self, q, n_probe):
         q = f32c(q)

@@ -3,7 +3,7 @@
 // HBM layout ("lane-interleaved blocks").  Every vector set that gets scanned — the coarse
 // centroid table and each inverted list — is stored in blocks of 64 vectors:
 //
-//     block[b] : float4 [dq][64]          dq = ceil(dim/4), zero padded
+//     block[b] : float4 [dq][64]          dq = 4*ceil(dim/16) quads, zero padded
 //     element (qd, lane).{x,y,z,w} = dims 4*qd .. 4*qd+3 of vector (64*b + lane)
 //
 // so that a wave64 reading quad qd of a block issues ONE global_load_dwordx4 covering a

@@ -9,6 +9,10 @@
 
 namespace vi {
 
+// quads (float4) per vector in the block layout: dims are zero-padded to a multiple of 16 so that
+// the scan kernel always consumes whole groups of 4 quads
+inline uint32_t layout_dq(uint32_t dim) { return ((dim + 15) / 16) * 4; }
+
 struct ScanArgs {
   const float4 *blocks;   // lane-interleaved blocks (device_index.hpp)
   uint32_t dq, dim;

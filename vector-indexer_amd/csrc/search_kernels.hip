@@ -28,6 +28,7 @@
 #include <memory>
 
 #include "device_index.hpp"
+#include "device_math.hpp"
 #include "scan.hpp"
 
 namespace vi {
@@ -106,90 +107,65 @@ struct WaveTopK {
 // Exact-order accumulators.  SCALAR: src/utils.rs:28-30.  LANES: src/kmeans.rs:377-419
 // (8-lane chunks, then one 4-lane chunk, then a scalar tail; reduce order see oracle header).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sq_add(float &acc, float q, float x) {
-  const float t = q - x;
-  acc = acc + t * t;  // -ffp-contract=off: separate v_mul_f32 / v_add_f32
-}
+// Accumulator state of QG (query, vector) pairs per lane.  add<T>() consumes quad T (0..3) of the
+// current group of 4 quads; `qi` is the absolute quad index (wave-uniform).
+template <int ORDER, int QG>
+struct Acc;
 
 template <int QG>
-__device__ __forceinline__ void accumulate_scalar(const float4 *__restrict__ vb, const float4 *lq,
-                                                  uint32_t dq, float (&out)[QG]) {
-  float acc[QG];
+struct Acc<VI_ORDER_SCALAR, QG> {
+  float a[QG];
+  __device__ __forceinline__ void reset() {
 #pragma unroll
-  for (int j = 0; j < QG; ++j) acc[j] = 0.0f;
-#pragma unroll 4
-  for (uint32_t qd = 0; qd < dq; ++qd) {
-    const float4 x = vb[(size_t)qd * kWave];
-#pragma unroll
-    for (int j = 0; j < QG; ++j) {
-      const float4 q = lq[j * dq + qd];
-      sq_add(acc[j], q.x, x.x);
-      sq_add(acc[j], q.y, x.y);
-      sq_add(acc[j], q.z, x.z);
-      sq_add(acc[j], q.w, x.w);
-    }
+    for (int j = 0; j < QG; ++j) a[j] = 0.0f;
   }
-#pragma unroll
-  for (int j = 0; j < QG; ++j) out[j] = acc[j];
-}
+  template <int T>
+  __device__ __forceinline__ void add(int j, uint32_t, uint32_t, bool, const float4 &q, const float4 &x) {
+    sq_add(a[j], q.x, x.x);
+    sq_add(a[j], q.y, x.y);
+    sq_add(a[j], q.z, x.z);
+    sq_add(a[j], q.w, x.w);
+  }
+  __device__ __forceinline__ float finish(int j) const { return a[j]; }
+};
 
 template <int QG>
-__device__ __forceinline__ void accumulate_lanes(const float4 *__restrict__ vb, const float4 *lq,
-                                                 uint32_t dq, uint32_t dim, float (&out)[QG]) {
-  float a8[QG][8];
-#pragma unroll
-  for (int j = 0; j < QG; ++j)
-#pragma unroll
-    for (int l = 0; l < 8; ++l) a8[j][l] = 0.0f;
-  const uint32_t n8 = dim / 8;
-#pragma unroll 2
-  for (uint32_t c = 0; c < n8; ++c) {
-    const float4 x0 = vb[(size_t)(2 * c) * kWave];
-    const float4 x1 = vb[(size_t)(2 * c + 1) * kWave];
+struct Acc<VI_ORDER_LANES, QG> {
+  float a8[QG][8], a4[QG][4], tail[QG];
+  __device__ __forceinline__ void reset() {
 #pragma unroll
     for (int j = 0; j < QG; ++j) {
-      const float4 q0 = lq[j * dq + 2 * c];
-      const float4 q1 = lq[j * dq + 2 * c + 1];
-      sq_add(a8[j][0], q0.x, x0.x); sq_add(a8[j][1], q0.y, x0.y);
-      sq_add(a8[j][2], q0.z, x0.z); sq_add(a8[j][3], q0.w, x0.w);
-      sq_add(a8[j][4], q1.x, x1.x); sq_add(a8[j][5], q1.y, x1.y);
-      sq_add(a8[j][6], q1.z, x1.z); sq_add(a8[j][7], q1.w, x1.w);
+#pragma unroll
+      for (int l = 0; l < 8; ++l) a8[j][l] = 0.0f;
+      a4[j][0] = a4[j][1] = a4[j][2] = a4[j][3] = 0.0f;
+      tail[j] = 0.0f;
     }
   }
-  uint32_t qd = 2 * n8;
-  uint32_t rem = dim - 8 * n8;
-  float a4[QG][4], tail[QG];
-#pragma unroll
-  for (int j = 0; j < QG; ++j) { a4[j][0] = a4[j][1] = a4[j][2] = a4[j][3] = 0.0f; tail[j] = 0.0f; }
-  if (rem >= 4) {  // one f32x4 chunk (kmeans.rs:399-408)
-    const float4 x = vb[(size_t)qd * kWave];
-#pragma unroll
-    for (int j = 0; j < QG; ++j) {
-      const float4 q = lq[j * dq + qd];
+  // n8x2 = 2*(dim/8): quads below it feed the 8 lane accumulators (kmeans.rs:387-396); the next
+  // quad is the f32x4 chunk if at least 4 dims remain (:399-408); what is left is the scalar
+  // tail (:411-416).  Zero padding contributes exact +0 wherever it lands.
+  template <int T>
+  __device__ __forceinline__ void add(int j, uint32_t qi, uint32_t n8x2, bool has4, const float4 &q,
+                                      const float4 &x) {
+    if (qi < n8x2) {
+      constexpr int h = (T & 1) * 4;
+      sq_add(a8[j][h + 0], q.x, x.x); sq_add(a8[j][h + 1], q.y, x.y);
+      sq_add(a8[j][h + 2], q.z, x.z); sq_add(a8[j][h + 3], q.w, x.w);
+    } else if (qi == n8x2 && has4) {
       sq_add(a4[j][0], q.x, x.x); sq_add(a4[j][1], q.y, x.y);
       sq_add(a4[j][2], q.z, x.z); sq_add(a4[j][3], q.w, x.w);
-    }
-    qd += 1;
-    rem -= 4;
-  }
-  if (rem > 0) {  // scalar tail (kmeans.rs:411-416); zero padding adds exact +0
-    const float4 x = vb[(size_t)qd * kWave];
-#pragma unroll
-    for (int j = 0; j < QG; ++j) {
-      const float4 q = lq[j * dq + qd];
+    } else {
       sq_add(tail[j], q.x, x.x); sq_add(tail[j], q.y, x.y);
       sq_add(tail[j], q.z, x.z); sq_add(tail[j], q.w, x.w);
     }
   }
-#pragma unroll
-  for (int j = 0; j < QG; ++j) {
+  __device__ __forceinline__ float finish(int j) const {
     const float lo = ((a8[j][0] + a8[j][1]) + a8[j][2]) + a8[j][3];
     const float hi = ((a8[j][4] + a8[j][5]) + a8[j][6]) + a8[j][7];
-    const float r8 = lo + hi;
     const float r4 = ((a4[j][0] + a4[j][1]) + a4[j][2]) + a4[j][3];
-    out[j] = (r8 + r4) + tail[j];
+    return ((lo + hi) + r4) + tail[j];
   }
-}
+};
 
 // ------------------------------------------------------------------------------------------
 // scan kernel
@@ -262,17 +238,47 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
   for (int j = 0; j < QG; ++j) sel[j].init();
   const int K = (int)a.K;
 
-  for (uint32_t b = b0; b < b1; ++b) {
-    const float4 *vb = a.blocks + ((size_t)(fb + b) * a.dq) * kWave + lane;
-    float dist[QG];
-    if (ORDER == VI_ORDER_SCALAR) accumulate_scalar<QG>(vb, lq, a.dq, dist);
-    else accumulate_lanes<QG>(vb, lq, a.dq, a.dim, dist);
-    const uint32_t pos = b * kWave + lane;
-    const bool valid = pos < len;
-    const uint32_t p = valid ? pos : kNoPos;
+  // Flat software-pipelined sweep over (block, group-of-4-quads): the next group's four
+  // global_load_dwordx4 are issued before the current group is consumed, also across block
+  // boundaries, so the selection step of a block overlaps the first loads of the next one.
+  const uint32_t gpb = a.dq >> 2;  // dq is a multiple of 4 (layout pads dims to 16)
+  const uint32_t total = (b1 - b0) * gpb;
+  const uint32_t n8x2 = 2 * (a.dim / 8);
+  const bool has4 = (a.dim - 4 * n8x2) >= 4;
+  const float4 *vbase = a.blocks + ((size_t)(fb + b0) * a.dq) * kWave + lane;
+  Acc<ORDER, QG> acc;
+  acc.reset();
+  float4 xn0, xn1, xn2, xn3;
+  if (total) {
+    xn0 = vbase[0]; xn1 = vbase[kWave]; xn2 = vbase[2 * kWave]; xn3 = vbase[3 * kWave];
+  }
+  uint32_t gq = 0, blk = b0;
+  for (uint32_t g = 0; g < total; ++g) {
+    const float4 x0 = xn0, x1 = xn1, x2 = xn2, x3 = xn3;
+    if (g + 1 < total) {
+      const float4 *nx = vbase + (size_t)(g + 1) * 4 * kWave;  // groups are contiguous in memory
+      xn0 = nx[0]; xn1 = nx[kWave]; xn2 = nx[2 * kWave]; xn3 = nx[3 * kWave];
+    }
+    const uint32_t qi = gq * 4;
 #pragma unroll
-    for (int j = 0; j < QG; ++j)
-      if (j < (int)nqi) sel[j].offer(valid ? dist[j] : INFINITY, p, K);
+    for (int j = 0; j < QG; ++j) acc.template add<0>(j, qi + 0, n8x2, has4, lq[j * a.dq + qi + 0], x0);
+#pragma unroll
+    for (int j = 0; j < QG; ++j) acc.template add<1>(j, qi + 1, n8x2, has4, lq[j * a.dq + qi + 1], x1);
+#pragma unroll
+    for (int j = 0; j < QG; ++j) acc.template add<2>(j, qi + 2, n8x2, has4, lq[j * a.dq + qi + 2], x2);
+#pragma unroll
+    for (int j = 0; j < QG; ++j) acc.template add<3>(j, qi + 3, n8x2, has4, lq[j * a.dq + qi + 3], x3);
+    if (++gq == gpb) {
+      const uint32_t pos = blk * kWave + lane;
+      const bool valid = pos < len;
+      const uint32_t p = valid ? pos : kNoPos;
+#pragma unroll
+      for (int j = 0; j < QG; ++j)
+        if (j < (int)nqi) sel[j].offer(valid ? acc.finish(j) : INFINITY, p, K);
+      acc.reset();
+      gq = 0;
+      ++blk;
+    }
   }
 
   if (lane < K) {
@@ -579,25 +585,7 @@ __global__ void l2sq_pairs_kernel(const float *a, const float *b, uint64_t n, ui
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float *p = a + i * d, *c = b + i * d;
-  if (order == VI_ORDER_SCALAR) {
-    float acc = 0.0f;
-    for (uint32_t j = 0; j < d; ++j) sq_add(acc, p[j], c[j]);
-    out[i] = acc;
-    return;
-  }
-  float a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, tail = 0.0f;
-  uint32_t j = 0;
-  for (; j + 8 <= d; j += 8)
-#pragma unroll
-    for (int l = 0; l < 8; ++l) sq_add(a8[l], p[j + l], c[j + l]);
-  for (; j + 4 <= d; j += 4)
-#pragma unroll
-    for (int l = 0; l < 4; ++l) sq_add(a4[l], p[j + l], c[j + l]);
-  for (; j < d; ++j) sq_add(tail, p[j], c[j]);
-  const float lo = ((a8[0] + a8[1]) + a8[2]) + a8[3];
-  const float hi = ((a8[4] + a8[5]) + a8[6]) + a8[7];
-  const float r4 = ((a4[0] + a4[1]) + a4[2]) + a4[3];
-  out[i] = ((lo + hi) + r4) + tail;
+  out[i] = order == VI_ORDER_SCALAR ? l2sq_scalar_dev(p, c, d) : l2sq_lanes_dev(p, c, d);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -804,7 +792,7 @@ static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, ui
   VI_HIP(hipSetDevice(device));
   ix->device = device;
   ix->dim = dim;
-  ix->dq = (dim + 3) / 4;
+  ix->dq = layout_dq(dim);
   ix->nlists = nlists;
   if (!ix->stream) VI_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   for (auto &e : ix->ev)
@@ -930,6 +918,13 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     return VI_OK;
   }
 
+  VI_TRY(ws.cnt.reserve(2 * nlists));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  VI_TRY(ws.run_dist.reserve(nq * P * K));
+  VI_TRY(ws.run_pos.reserve(nq * P * K));
+  // runs of lists that are not resident here (other rank / unreadable shard) stay empty
+  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
+
   const bool timing = ix.timing;
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
 
@@ -951,8 +946,6 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   // ---- 2. merge -> probes, shard order, histogram ----
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
-  VI_TRY(ws.cnt.reserve(2 * nlists));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
   {
     CoarseMergeArgs a{ws.crun_dist.p, ws.crun_pos.p, (uint32_t)nq, S, P, ix.list_shard.p, ix.list_len.p,
                       ws.probes.p, ws.gorder.p, ws.cnt.p};
@@ -978,9 +971,6 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
   // ---- 4. list scan ----
-  VI_TRY(ws.run_dist.reserve(nq * P * K));
-  VI_TRY(ws.run_pos.reserve(nq * P * K));
-  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
   {
     ScanArgs a{};
     a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;

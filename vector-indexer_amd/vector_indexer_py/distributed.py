@@ -1,0 +1,89 @@
+"""Multi-GPU search: one process per GPU, inverted lists partitioned by shard, ONE all-gather.
+
+Rank r keeps the lists of shards s with s % world == r resident (vi_config.rank/world_size); the
+coarse table is replicated so every rank derives the same probe list and the same candidate-order
+keys.  Per query each rank returns its local top-k (D, I, tie); the three arrays are exchanged with
+torch.distributed.all_gather (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
+protocol tests) and merged on (dist, tie), which reproduces the single-GPU stable order exactly.
+
+The reference has no distributed mode (its "two-level sharding" only groups files,
+src/ivf_index.rs:104-164); this is the MI355X-native extension BASELINE.json's north_star asks for.
+"""
+import numpy as np
+
+
+def shard_owner(shard_id: int, world: int) -> int:
+    """placement rule shared by vi_indexer_load (csrc/search_kernels.hip) and the tests"""
+    return int(shard_id) % max(int(world), 1)
+
+
+class ShardedSearcher:
+    """local_search(xq, k, n_probe) -> (D, I, tie) tensors on this rank's device;
+    merge(D_all, I_all, T_all) -> (D, I) with *_all shaped [world, nq, k]."""
+
+    def __init__(self, local_search, merge, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._local_search = local_search
+        self._merge = merge
+        self._group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def search(self, xq, k, n_probe):
+        import torch
+        D, I, T = self._local_search(xq, k, n_probe)
+        if self.world == 1:
+            return D, I
+        nq, k = D.shape
+        # concatenated output form (world*nq, k): accepted by both the RCCL and the gloo backend
+        Dg = torch.empty((self.world * nq, k), dtype=D.dtype, device=D.device)
+        Ig = torch.empty((self.world * nq, k), dtype=I.dtype, device=I.device)
+        Tg = torch.empty((self.world * nq, k), dtype=T.dtype, device=T.device)
+        self._dist.all_gather_into_tensor(Dg, D.contiguous(), group=self._group)
+        self._dist.all_gather_into_tensor(Ig, I.contiguous(), group=self._group)
+        self._dist.all_gather_into_tensor(Tg, T.contiguous(), group=self._group)
+        shape = (self.world, nq, k)
+        return self._merge(Dg.view(shape), Ig.view(shape), Tg.view(shape))
+
+
+def gpu_searcher(index, device_index: int, group=None) -> ShardedSearcher:
+    """ShardedSearcher over a vector_indexer_py.VectorIndex loaded with rank/world_size."""
+    import torch
+    from . import _native
+
+    dev = torch.device("cuda", device_index)
+
+    def local_search(xq, k, n_probe):
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        T = torch.empty((nq, k), dtype=torch.int64, device=dev)  # u64 bit pattern
+        index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), T.data_ptr())
+        return D, I, T
+
+    def merge(Dg, Ig, Tg):
+        world, nq, k = Dg.shape
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        _native.check(_native.lib().vi_merge_partials_device(device_index, nq, k, world, Dg.data_ptr(), Ig.data_ptr(),
+                                                             Tg.data_ptr(), D.data_ptr(), I.data_ptr()))
+        return D, I
+
+    return ShardedSearcher(local_search, merge, group)
+
+
+def merge_partials_reference(Dg, Ig, Tg):
+    """numpy statement of the merge rule (used by the CPU protocol tests)."""
+    Dg, Ig = np.asarray(Dg), np.asarray(Ig)
+    Tg = np.asarray(Tg).view(np.uint64) if np.asarray(Tg).dtype == np.int64 else np.asarray(Tg)
+    world, nq, k = Dg.shape
+    D = np.full((nq, k), np.inf, dtype=np.float32)
+    I = np.full((nq, k), -1, dtype=np.int64)
+    for q in range(nq):
+        d, i, t = Dg[:, q].reshape(-1), Ig[:, q].reshape(-1), Tg[:, q].reshape(-1)
+        live = i >= 0
+        order = np.lexsort((t[live], d[live].view(np.uint32)))  # (dist bits, tie): dists are >= +0
+        m = min(k, order.size)
+        D[q, :m], I[q, :m] = d[live][order[:m]], i[live][order[:m]]
+    return D, I
