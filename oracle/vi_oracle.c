@@ -832,26 +832,62 @@ done:
   return rc;
 }
 
+/* Preload every list of every shard into RAM (one pass per shard file).  A shard that cannot be
+ * read, has a mismatching id/dimension, or lacks one of its centroids leaves all its lists
+ * unavailable — the reference drops the whole shard result in that case (:253-254, :257-265). */
 static void index_load_lists(orc_index *ix, const char *shards_dir) {
   uint64_t k = ix->k;
   ix->list_len = (uint64_t *)calloc(k + 1, sizeof(uint64_t));
   ix->list_meta = (uint64_t **)calloc(k + 1, sizeof(uint64_t *));
   ix->list_vec = (float **)calloc(k + 1, sizeof(float *));
   ix->list_ok = (uint8_t *)calloc(k + 1, 1);
-  for (uint64_t c = 0; c < k; ++c) {
-    uint64_t cnt = 0;
-    uint32_t dim = 0;
-    uint64_t id = c;
-    int rc = orc_shard_get_centroid_vectors_from(shards_dir, ix->c2s[c], &id, 1, &dim, &cnt,
-                                                 NULL, NULL, NULL);
-    if (rc != ORC_OK || dim != ix->dim) continue;
-    ix->list_meta[c] = (uint64_t *)malloc(sizeof(uint64_t) * 3 * (size_t)(cnt + 1));
-    ix->list_vec[c] = (float *)malloc(sizeof(float) * (size_t)(cnt * dim + 1));
-    rc = orc_shard_get_centroid_vectors_from(shards_dir, ix->c2s[c], &id, 1, &dim, &cnt, NULL,
-                                             ix->list_meta[c], ix->list_vec[c]);
-    if (rc != ORC_OK) continue;
-    ix->list_len[c] = cnt;
-    ix->list_ok[c] = 1;
+  uint64_t nshards = orc_index_num_shards(ix);
+  size_t dims = ix->dim, vsz = dims * 4, cpad = (8 - (vsz % 8)) % 8;
+  size_t stride = sizeof(vector_meta) + vsz + cpad;
+  for (uint64_t s = 0; s < nshards; ++s) {
+    char path[4096];
+    snprintf(path, sizeof(path), "%s/shard_%llu.bin", shards_dir, (unsigned long long)s);
+    size_t len = 0;
+    uint8_t *buf = read_whole_file(path, &len);
+    if (!buf) continue;
+    shard_header h;
+    int ok = len >= sizeof(h);
+    if (ok) { memcpy(&h, buf, sizeof(h)); ok = h.shard_id == s && h.dimensions == ix->dim; }
+    if (ok) ok = h.index_offset <= len && (size_t)h.num_centroids * sizeof(centroid_index) <= len - h.index_offset;
+    /* first pass: every centroid of this shard must be present and in bounds */
+    for (uint64_t c = 0; ok && c < k; ++c) {
+      if (ix->c2s[c] != s) continue;
+      int found = 0;
+      for (uint32_t i = 0; i < h.num_centroids && !found; ++i) {
+        centroid_index e;
+        memcpy(&e, buf + h.index_offset + (size_t)i * sizeof(e), sizeof(e));
+        if (e.centroid_id != c) continue;
+        found = 1;
+        size_t need = vsz + cpad + (size_t)e.num_vectors * stride - (e.num_vectors ? cpad : 0);
+        if (e.data_offset > len || e.data_size > len - e.data_offset || need > e.data_size) ok = 0;
+      }
+      if (!found) ok = 0;
+    }
+    for (uint64_t c = 0; ok && c < k; ++c) {
+      if (ix->c2s[c] != s) continue;
+      for (uint32_t i = 0; i < h.num_centroids; ++i) {
+        centroid_index e;
+        memcpy(&e, buf + h.index_offset + (size_t)i * sizeof(e), sizeof(e));
+        if (e.centroid_id != c) continue;
+        uint64_t cnt = e.num_vectors;
+        ix->list_meta[c] = (uint64_t *)malloc(sizeof(uint64_t) * 3 * (size_t)(cnt + 1));
+        ix->list_vec[c] = (float *)malloc(sizeof(float) * (size_t)(cnt * dims + 1));
+        const uint8_t *rec = buf + e.data_offset + vsz + cpad;
+        for (uint64_t v = 0; v < cnt; ++v, rec += stride) {
+          memcpy(ix->list_meta[c] + 3 * v, rec, sizeof(vector_meta));
+          memcpy(ix->list_vec[c] + v * dims, rec + sizeof(vector_meta), vsz);
+        }
+        ix->list_len[c] = cnt;
+        ix->list_ok[c] = 1;
+        break;
+      }
+    }
+    free(buf);
   }
 }
 
