@@ -25,7 +25,23 @@ import sys
 import tempfile
 import time
 
-import numpy as np
+# libgomp reads these once, when torch first loads it: cap the CPU baseline's OpenMP team to the CPUs
+# this job may really use (the GPU box shows 256 cores to nproc but grants a 16-CPU share)
+def _usable_cpus():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cpus()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vector-indexer_amd"))
@@ -210,7 +226,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
         orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
-        threads = O.lib().orc_max_threads()
+        threads = min(O.lib().orc_max_threads(), O.usable_cpus())
         xq_h = xq.cpu().numpy()
         done, t0c, chunk = 0, time.perf_counter(), 500
         while time.perf_counter() - t0c < args.cpu_seconds and done < nq:

@@ -43,6 +43,9 @@ struct SearchWorkspace {
   DevBuf<uint32_t> cnt;         // [nlists] (#queries probing list) ; cursor = second half
   DevBuf<uint32_t> seg_start;   // [nlists+1]
   DevBuf<uint32_t> item_start;  // [nlists+1]
+  DevBuf<uint32_t> segrun_start;  // [nlists+1]
+  DevBuf<float> seg_run_dist;   // segment runs of long lists, merged by seg_merge_kernel
+  DevBuf<uint32_t> seg_run_pos;
   DevBuf<uint32_t> pairs;       // [nq*P] slot ids grouped by list
   DevBuf<float> run_dist;       // [nq*P][K]
   DevBuf<uint32_t> run_pos;

@@ -26,7 +26,24 @@ struct ScanArgs {
   // LISTS: items derived from the grouping arrays; slot = pairs[...] = q*P + rank
   const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs;
   uint32_t nlists, P;
+  // long lists are cut into <= 64 segments of >= segb0 blocks so that no work item is much
+  // longer than the others; segment runs of one (query, list) pair go to seg_run_* at
+  // (segrun_start[list] + pair_in_list * nseg + seg) and are merged by seg_merge_kernel
+  uint32_t segb0;
+  uint32_t no_select;  // experiment knob: replace top-k selection by a running min (wrong results)
+  const uint32_t *segrun_start;
+  float *seg_run_dist;
+  uint32_t *seg_run_pos;
 };
+
+// segmentation rule shared by the grouping, scan and segment-merge kernels
+__host__ __device__ inline uint32_t list_segments(uint32_t len, uint32_t segb0, uint32_t *segb) {
+  const uint32_t nblk = (len + 63) / 64;
+  uint32_t sb = (nblk + 63) / 64;
+  if (sb < segb0) sb = segb0;
+  *segb = sb;
+  return nblk == 0 ? 0u : (nblk + sb - 1) / sb;
+}
 
 // query-group width for a unit (table or list) probed by `avg_queries_per_unit` queries
 int pick_qg(uint32_t dq, double avg_queries_per_unit, int order);

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -37,6 +38,16 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
+// Minimum blocks (x64 vectors) per list segment.  Measured on the C2 workload (profiles/
+// r01_experiments.md): cutting lists finer than this costs more in repeated top-k warm-up than it
+// gains in load balance, so only extreme lists (> 16k vectors) are cut.
+constexpr uint32_t kSegBlocksDefault = 256;
+
+// tuning knobs for experiments (scripts/gpu_scan_bench.py); unset => defaults
+inline uint32_t env_u32(const char *name, uint32_t dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
 
 // ------------------------------------------------------------------------------------------
 // wave primitives
@@ -179,6 +190,7 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
   const uint32_t item = blockIdx.x * kWavesPerBlock + wave;
 
   uint32_t nqi, b0, b1, len, fb;
+  uint32_t nseg = 1, seg = 0, segrun0 = 0;
   uint32_t slot[QG], qid[QG];
   if (COARSE) {
     const uint32_t nqg = (a.nq + QG - 1) / QG;
@@ -204,7 +216,13 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
     }
     const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
-    const uint32_t j0 = (item - a.item_start[l]) * QG;
+    len = a.list_len[l];
+    uint32_t segb;
+    nseg = list_segments(len, a.segb0, &segb);
+    const uint32_t local = item - a.item_start[l];
+    const uint32_t chunk = local / nseg;
+    seg = local - chunk * nseg;
+    const uint32_t j0 = chunk * QG;
     nqi = min((uint32_t)QG, cnt - j0);
 #pragma unroll
     for (int j = 0; j < QG; ++j) {
@@ -212,10 +230,11 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
       slot[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
       qid[j] = slot[j] / a.P;
     }
-    len = a.list_len[l];
+    segrun0 = nseg > 1 ? a.segrun_start[l] + j0 * nseg + seg : 0u;
     fb = a.first_block[l];
-    b0 = 0;
-    b1 = (len + kWave - 1) / kWave;
+    const uint32_t nblk = (len + kWave - 1) / kWave;
+    b0 = seg * segb;
+    b1 = min(nblk, b0 + segb);
   }
 
   // stage the group's queries in this wave's LDS slice, zero padded to dq*4 floats
@@ -274,7 +293,11 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
       const uint32_t p = valid ? pos : kNoPos;
 #pragma unroll
       for (int j = 0; j < QG; ++j)
-        if (j < (int)nqi) sel[j].offer(valid ? acc.finish(j) : INFINITY, p, K);
+        if (j < (int)nqi) {
+          const float dj = valid ? acc.finish(j) : INFINITY;
+          if (a.no_select) { sel[j].d = fminf(sel[j].d, dj); }  // experiment knob: cost of selection
+          else sel[j].offer(dj, p, K);
+        }
       acc.reset();
       gq = 0;
       ++blk;
@@ -285,9 +308,66 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
 #pragma unroll
     for (int j = 0; j < QG; ++j)
       if (j < (int)nqi) {
-        a.run_dist[(size_t)slot[j] * K + lane] = sel[j].d;
-        a.run_pos[(size_t)slot[j] * K + lane] = sel[j].p;
+        if (COARSE || nseg == 1) {
+          a.run_dist[(size_t)slot[j] * K + lane] = sel[j].d;
+          a.run_pos[(size_t)slot[j] * K + lane] = sel[j].p;
+        } else {
+          const size_t r = (size_t)(segrun0 + (uint32_t)j * nseg) * K + lane;
+          a.seg_run_dist[r] = sel[j].d;
+          a.seg_run_pos[r] = sel[j].p;
+        }
       }
+  }
+}
+
+// merge the segment runs of every (query, list) pair whose list was cut into segments
+struct SegMergeArgs {
+  const uint32_t *seg_start, *segrun_start, *list_len, *pairs;
+  uint32_t nlists, segb0, K;
+  const float *seg_run_dist;
+  const uint32_t *seg_run_pos;
+  float *run_dist;
+  uint32_t *run_pos;
+};
+
+__global__ void __launch_bounds__(kBlockThreads) seg_merge_kernel(SegMergeArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t pi = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (pi >= a.seg_start[a.nlists]) return;
+  uint32_t lo = 0, hi = a.nlists;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.seg_start[mid] <= pi) lo = mid; else hi = mid;
+  }
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+  uint32_t segb;
+  const uint32_t nseg = list_segments(a.list_len[l], a.segb0, &segb);
+  if (nseg <= 1) return;
+  const uint32_t K = a.K;
+  const size_t base = ((size_t)a.segrun_start[l] + (size_t)(pi - a.seg_start[l]) * nseg + lane) * K;
+  uint32_t head = 0, hp = kNoPos;
+  float hd = INFINITY;
+  if ((uint32_t)lane < nseg) { hd = a.seg_run_dist[base]; hp = a.seg_run_pos[base]; }
+  float od = INFINITY;
+  uint32_t op = kNoPos;
+  for (uint32_t i = 0; i < K; ++i) {
+    // segments hold increasing positions, so (dist, segment) == (dist, position) order
+    const uint64_t key = (hp == kNoPos) ? ~0ull : (((uint64_t)__float_as_uint(hd) << 32) | (uint32_t)lane);
+    const uint64_t m = wave_min_u64(key);
+    if (m == ~0ull) break;
+    const int win = (int)(uint32_t)m;
+    const uint32_t wp = readlane_u(hp, win);
+    if ((uint32_t)lane == i) { od = __uint_as_float((uint32_t)(m >> 32)); op = wp; }
+    if (lane == win) {
+      ++head;
+      if (head < K) { hd = a.seg_run_dist[base + head]; hp = a.seg_run_pos[base + head]; }
+      else hp = kNoPos;
+    }
+  }
+  if ((uint32_t)lane < K) {
+    const size_t o = (size_t)a.pairs[pi] * K + lane;
+    a.run_dist[o] = od;
+    a.run_pos[o] = op;
   }
 }
 
@@ -351,44 +431,56 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 // ------------------------------------------------------------------------------------------
 // grouping (counting sort of (query, probe) pairs by list)
 // ------------------------------------------------------------------------------------------
-// single block: exclusive scans of cnt[] and ceil(cnt/QG); stats[0] = Σ cnt*len, stats[1] = items
+// single block: exclusive scans over the lists of
+//   seg_start    Σ cnt                      (pairs grouped by list)
+//   item_start   Σ ceil(cnt/QG) * nseg      (scan work items)
+//   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
+// stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
 __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
-                                                          uint32_t nlists, uint32_t qg, uint32_t *seg_start,
-                                                          uint32_t *item_start, uint64_t *stats) {
-  __shared__ uint32_t s_seg[1024], s_item[1024];
+                                                          uint32_t nlists, uint32_t qg, uint32_t segb0,
+                                                          uint32_t *seg_start, uint32_t *item_start,
+                                                          uint32_t *segrun_start, uint64_t *stats) {
+  __shared__ uint32_t s_seg[1024], s_item[1024], s_run[1024];
   __shared__ unsigned long long s_vec[1024];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
-  uint32_t seg = 0, item = 0;
+  uint32_t seg = 0, item = 0, run = 0;
   unsigned long long vec = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint32_t c = cnt[l];
+    uint32_t segb;
+    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg += c;
-    item += (c + qg - 1) / qg;
+    item += ((c + qg - 1) / qg) * ns;
+    run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * list_len[l];
   }
-  s_seg[t] = seg; s_item[t] = item; s_vec[t] = vec;
+  s_seg[t] = seg; s_item[t] = item; s_run[t] = run; s_vec[t] = vec;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t a = 0, b = 0;
+    uint32_t a = 0, b = 0, r = 0;
     unsigned long long c = 0;
-    if (t >= off) { a = s_seg[t - off]; b = s_item[t - off]; c = s_vec[t - off]; }
+    if (t >= off) { a = s_seg[t - off]; b = s_item[t - off]; r = s_run[t - off]; c = s_vec[t - off]; }
     __syncthreads();
-    s_seg[t] += a; s_item[t] += b; s_vec[t] += c;
+    s_seg[t] += a; s_item[t] += b; s_run[t] += r; s_vec[t] += c;
     __syncthreads();
   }
-  uint32_t rs = s_seg[t] - seg, ri = s_item[t] - item;
+  uint32_t rs = s_seg[t] - seg, ri = s_item[t] - item, rr = s_run[t] - run;
   for (uint32_t l = beg; l < end; ++l) {
     const uint32_t c = cnt[l];
-    seg_start[l] = rs; item_start[l] = ri;
-    rs += c; ri += (c + qg - 1) / qg;
+    uint32_t segb;
+    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
+    seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
+    rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
   }
   if (t == 1023) {
     seg_start[nlists] = s_seg[1023];
     item_start[nlists] = s_item[1023];
+    segrun_start[nlists] = s_run[1023];
     stats[0] = s_vec[1023];
     stats[1] = s_item[1023];
+    stats[2] = s_run[1023];
   }
 }
 
@@ -609,9 +701,11 @@ vi_status launch_scan_t(const ScanArgs &a, uint32_t nitems_upper, hipStream_t st
 // Chosen so that QG*dq float4 per wave stays within the 160 KiB LDS of a CU at 4 waves/block.
 int pick_qg(uint32_t dq, double avg_queries_per_unit, int order) {
   const int cap = order == VI_ORDER_LANES ? 4 : 8;
+  // QG=8 halves the block re-reads but needs 154 VGPRs (3 waves/SIMD); QG=4 (102 VGPRs, 4 waves/SIMD)
+  // measured 10 % faster on the C2 workload (profiles/r01_experiments.md)
   int qg = 1;
   if (avg_queries_per_unit >= 3.0) qg = 4;
-  if (avg_queries_per_unit >= 6.0) qg = 8;
+  (void)cap;
   qg = std::min(qg, cap);
   while (qg > 1 && (size_t)kWavesPerBlock * qg * dq * sizeof(float4) > 96 * 1024) qg = (qg == 8) ? 4 : 1;
   return qg;
@@ -956,12 +1050,18 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
   // ---- 3. group (query,probe) pairs by list ----
   const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
-  const int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
+  int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
+  {
+    const uint32_t f = env_u32("VI_FORCE_QG", 0);
+    if (f == 1 || f == 4 || (f == 8 && ix.order == VI_ORDER_SCALAR)) qg_l = (int)f;
+  }
+  const uint32_t kSegBlocks = std::max<uint32_t>(1, env_u32("VI_SEG_BLOCKS", kSegBlocksDefault));
   VI_TRY(ws.seg_start.reserve(nlists + 1));
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(nq * P));
+  VI_TRY(ws.segrun_start.reserve(nlists + 1));
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg_l, ws.seg_start.p, ws.item_start.p, ws.stats.p);
+                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
   VI_HIP(hipGetLastError());
   {
     const uint32_t total = (uint32_t)(nq * P);
@@ -969,6 +1069,15 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
                        ix.list_len.p, ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
     VI_HIP(hipGetLastError());
   }
+  // exact work-item / segment-run counts size the scan grid and its scratch
+  uint64_t hstats[3] = {0, 0, 0};
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
+  stt.scanned_vectors = hstats[0];
+  stt.scan_items = hstats[1];
+  const uint64_t nsegruns = hstats[2];
+  VI_TRY(ws.seg_run_dist.reserve(nsegruns * K));
+  VI_TRY(ws.seg_run_pos.reserve(nsegruns * K));
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
   // ---- 4. list scan ----
   {
@@ -977,8 +1086,18 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P;
-    const uint64_t upper = (nq * P + qg_l - 1) / qg_l + std::min<uint64_t>(nlists, nq * P);
-    VI_TRY(launch_scan(a, qg_l, ix.order, false, (uint32_t)upper, st));
+    a.segb0 = kSegBlocks; a.segrun_start = ws.segrun_start.p;
+    a.no_select = env_u32("VI_NO_SELECT", 0);
+    a.seg_run_dist = ws.seg_run_dist.p; a.seg_run_pos = ws.seg_run_pos.p;
+    VI_TRY(launch_scan(a, qg_l, ix.order, false, (uint32_t)hstats[1], st));
+    if (nsegruns) {
+      SegMergeArgs m{ws.seg_start.p, ws.segrun_start.p, ix.list_len.p, ws.pairs.p, (uint32_t)nlists, kSegBlocks, K,
+                     ws.seg_run_dist.p, ws.seg_run_pos.p, ws.run_dist.p, ws.run_pos.p};
+      const uint32_t npairs = (uint32_t)(nq * P);
+      hipLaunchKernelGGL(seg_merge_kernel, dim3((npairs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads),
+                         0, st, m);
+      VI_HIP(hipGetLastError());
+    }
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 5. final merge ----
@@ -1009,11 +1128,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
       for (uint64_t i = 0; i < nq; ++i) io.counts[i] = c32[i];
     }
   }
-  uint64_t hstats[2] = {0, 0};
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));
-  stt.scanned_vectors = hstats[0];
-  stt.scan_items = hstats[1];
   if (timing) {
     (void)hipEventElapsedTime(&stt.ms_coarse, ix.ev[0], ix.ev[1]);
     (void)hipEventElapsedTime(&stt.ms_group, ix.ev[1], ix.ev[2]);
