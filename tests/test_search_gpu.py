@@ -165,3 +165,38 @@ def test_missing_shard_file_is_skipped(tmp_path):
     gpu = vip.load(idx, sh, 16)
     assert gpu.num_vectors < 3000
     check_parity(orc, gpu, X[:200], 10, 12)
+
+
+def test_generic_path_large_k_and_nprobe(tmp_path):
+    """k > 64 or n_probe > 64 leave the wave-select fast path: dump every distance + stable sort, as the
+    reference states it (ivf_index.rs:205-266).  The harness default is K=100 (run_faiss_bench.sh:54)."""
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((9000, 24)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X)          # 94 lists > 64
+    assert gpu.num_centroids > 64
+    Q = np.concatenate([rng.standard_normal((120, 24)).astype(np.float32), X[:30]])
+    for k, n_probe in [(100, 16), (65, 64), (10, 65), (10, 94), (200, 94), (1000, 10_000), (3, 80)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+    # exhaustive probe + huge k: every vector comes back exactly once, k clamped to max_k = 10 000
+    D, I = gpu.search_sync(Q[:3], 20_000, 20_000)
+    assert D.shape == (3, 20_000)
+    assert (np.sort(I[:, :9000], axis=1) == np.arange(9000)).all() and (I[:, 9000:] == -1).all()
+    assert (np.diff(D[:, :9000], axis=1) >= 0).all()
+
+
+def test_generic_path_equals_fast_path(tmp_path, monkeypatch):
+    rng = np.random.default_rng(22)
+    base = rng.integers(-3, 4, size=(2500, 10)).astype(np.float32)
+    X = np.concatenate([base, base[:700]])              # duplicates: tie order must also agree
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=50)
+    Q = np.concatenate([base[:100], rng.standard_normal((100, 10)).astype(np.float32)])
+    for k, n_probe in [(10, 8), (64, 50), (1, 1), (33, 7)]:
+        fast = gpu.search_sync(Q, k, n_probe)
+        monkeypatch.setenv("VI_FORCE_GENERIC", "1")
+        gen = gpu.search_sync(Q, k, n_probe, include_vectors=True)
+        monkeypatch.delenv("VI_FORCE_GENERIC")
+        assert (fast[1] == gen[1]).all() and (bits(fast[0]) == bits(gen[0])).all()
+        check_parity(orc, gpu, Q, k, n_probe)
+        for qi in (0, 57):
+            for j in range(min(k, 5)):
+                assert gen[2][qi, j].tobytes() == X[np.nonzero(np.arange(len(X)) == gen[1][qi, j])[0][0]].tobytes()

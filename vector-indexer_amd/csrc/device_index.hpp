@@ -57,8 +57,8 @@ struct SearchWorkspace {
   DevBuf<uint64_t> stats;       // device-side counters
   DevBuf<float> V;
   // generic (large k / n_probe) path
-  DevBuf<uint64_t> sort_keys;
-  DevBuf<uint32_t> cand_off;
+  DevBuf<uint64_t> sort_keys, order_keys, total;
+  DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };
 
 struct DeviceIndex {

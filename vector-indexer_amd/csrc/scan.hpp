@@ -31,6 +31,12 @@ struct ScanArgs {
   // (segrun_start[list] + pair_in_list * nseg + seg) and are merged by seg_merge_kernel
   uint32_t segb0;
   uint32_t no_select;  // experiment knob: replace top-k selection by a running min (wrong results)
+  // dump mode (generic_search.hip): instead of selecting, write one key per candidate,
+  // (dist bits << 32) | index, at dump_keys[row * dump_row + index]; COARSE: row = query,
+  // index = centroid; LISTS: row = slot / P, index = dump_off[slot] + position in list
+  uint64_t *dump_keys;
+  uint64_t dump_row;
+  const uint32_t *dump_off;
   const uint32_t *segrun_start;
   float *seg_run_dist;
   uint32_t *seg_run_pos;

@@ -295,8 +295,17 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
       for (int j = 0; j < QG; ++j)
         if (j < (int)nqi) {
           const float dj = valid ? acc.finish(j) : INFINITY;
-          if (a.no_select) { sel[j].d = fminf(sel[j].d, dj); }  // experiment knob: cost of selection
-          else sel[j].offer(dj, p, K);
+          if (a.dump_keys) {  // generic path: every candidate is written out, nothing is selected
+            if (valid) {
+              const uint32_t idx = COARSE ? pos : a.dump_off[slot[j]] + pos;
+              const uint64_t row = COARSE ? (uint64_t)qid[j] : (uint64_t)(slot[j] / a.P);
+              a.dump_keys[row * a.dump_row + idx] = ((uint64_t)__float_as_uint(dj) << 32) | idx;
+            }
+          } else if (a.no_select) {
+            sel[j].d = fminf(sel[j].d, dj);  // experiment knob: cost of selection
+          } else {
+            sel[j].offer(dj, p, K);
+          }
         }
       acc.reset();
       gq = 0;
@@ -304,7 +313,7 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
     }
   }
 
-  if (lane < K) {
+  if (lane < K && !a.dump_keys) {
 #pragma unroll
     for (int j = 0; j < QG; ++j)
       if (j < (int)nqi) {
@@ -482,6 +491,13 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     stats[1] = s_item[1023];
     stats[2] = s_run[1023];
   }
+}
+
+__global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t n, uint32_t *cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t l = probes[i];
+  if (l != kNoPos && list_len[l] > 0) atomicAdd(&cnt[l], 1u);
 }
 
 __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, const uint32_t *seg_start,
@@ -957,6 +973,10 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
   return VI_OK;
 }
 
+vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
+                                      float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
+                                      hipStream_t st);
+
 // ------------------------------------------------------------------------------------------
 // search pipeline (fast path: n_probe_eff <= 64 and k <= 64)
 // ------------------------------------------------------------------------------------------
@@ -972,9 +992,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   if (nq * std::max<uint64_t>(k, 64) > 0x7FFFFFFFull) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   const uint32_t P = (uint32_t)std::min<uint64_t>(io.n_probe, nlists);  // take(n_probe) (ivf_index.rs:216-220)
   const uint32_t K = (uint32_t)std::min<uint64_t>(k, kMaxSelect);
-  if (P > kMaxSelect || k > kMaxSelect)
-    return fail(VI_ERR_OTHER, "k=%llu / n_probe=%u beyond the wave-select fast path (generic path not built yet)",
-                (unsigned long long)k, P);
+  const bool generic = P > kMaxSelect || k > kMaxSelect || env_u32("VI_FORCE_GENERIC", 0) != 0;
 
   // ---- outputs / queries on device ----
   const float *Qd = io.queries;
@@ -1012,6 +1030,10 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     return VI_OK;
   }
 
+  const bool timing = ix.timing && !generic;
+  if (generic) {
+    VI_TRY(device_index_search_generic(ix, Qd, nq, k, P, Dd, Id, Td, slots, ws.counts.p, st));
+  } else {
   VI_TRY(ws.cnt.reserve(2 * nlists));
   VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
   VI_TRY(ws.run_dist.reserve(nq * P * K));
@@ -1019,7 +1041,6 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   // runs of lists that are not resident here (other rank / unreadable shard) stay empty
   VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
 
-  const bool timing = ix.timing;
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
 
   // ---- 1. coarse scan over the centroid table ----
@@ -1109,6 +1130,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+  }
 
   // ---- results ----
   if (!io.on_device) {
@@ -1136,6 +1158,32 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     (void)hipEventElapsedTime(&stt.ms_merge, ix.ev[3], ix.ev[4]);
     (void)hipEventElapsedTime(&stt.ms_total, ix.ev[0], ix.ev[4]);
   }
+  return VI_OK;
+}
+
+// Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
+// the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
+vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
+                          uint64_t hstats[3], hipStream_t st) {
+  SearchWorkspace &ws = ix.ws;
+  const uint64_t nlists = ix.nlists;
+  const uint32_t total = (uint32_t)(nq * P);
+  VI_TRY(ws.cnt.reserve(2 * nlists));
+  VI_TRY(ws.seg_start.reserve(nlists + 1));
+  VI_TRY(ws.item_start.reserve(nlists + 1));
+  VI_TRY(ws.segrun_start.reserve(nlists + 1));
+  VI_TRY(ws.pairs.reserve(total));
+  VI_TRY(ws.stats.reserve(8));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total,
+                     ws.cnt.p);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
+                     (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
+  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
+                     ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
   return VI_OK;
 }
 
