@@ -33,16 +33,17 @@ __device__ __forceinline__ void cmp_swap(uint64_t &x, uint64_t &y, bool asc) {
 }
 
 // sort every kChunk-aligned chunk completely (all stages with k2 <= kChunk); L % kChunk == 0
-__global__ void __launch_bounds__(1024) bitonic_local_sort_kernel(uint64_t *keys) {
+__global__ void __launch_bounds__(1024) bitonic_local_sort_kernel(uint64_t *keys, uint32_t logL) {
   __shared__ uint64_t s[kChunk];
   const uint64_t base = (uint64_t)blockIdx.x * kChunk;
+  const uint64_t in_row = base & ((1ull << logL) - 1);  // sort direction follows the index INSIDE the row
   for (uint32_t i = threadIdx.x; i < kChunk; i += 1024) s[i] = keys[base + i];
   __syncthreads();
   for (uint32_t k2 = 2; k2 <= kChunk; k2 <<= 1)
     for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
       const uint32_t i = threadIdx.x;  // kChunk/2 == 1024 pairs
       const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-      const bool asc = (((base + a) & k2) == 0);
+      const bool asc = (((in_row + a) & k2) == 0);
       cmp_swap(s[a], s[a + j], asc);
       __syncthreads();
     }
@@ -84,7 +85,7 @@ vi_status sort_rows(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream_t s
   const uint64_t L = 1ull << logL, total = nrows * L;
   if (total == 0) return VI_OK;
   const uint32_t nchunks = (uint32_t)(total / kChunk);
-  hipLaunchKernelGGL(bitonic_local_sort_kernel, dim3(nchunks), dim3(1024), 0, st, keys);
+  hipLaunchKernelGGL(bitonic_local_sort_kernel, dim3(nchunks), dim3(1024), 0, st, keys, logL);
   for (uint64_t k2 = 2ull * kChunk; k2 <= L; k2 <<= 1) {
     for (uint64_t j = k2 >> 1; j >= kChunk; j >>= 1) {
       const uint64_t npairs = total / 2;
@@ -117,7 +118,7 @@ __global__ void shard_order_keys_kernel(const uint32_t *probes, const uint32_t *
   const uint32_t q = blockIdx.x;
   for (uint32_t s = threadIdx.x; s < nshards; s += blockDim.x) fa[s] = kNoPos;
   __syncthreads();
-  for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) atomicMin(&fa[list_shard[probes[(size_t)q * P + r]]], r);
+  for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) atomicMin(&fa[list_shard[probes[(size_t)q * P + r]]], r);  // probes < nlists: rows hold >= P real keys
   __syncthreads();
   const uint32_t Lp = 1u << logLp;
   for (uint32_t r = threadIdx.x; r < Lp; r += blockDim.x)
