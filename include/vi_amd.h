@@ -14,6 +14,10 @@
  *   - vi_status mirrors the std::io::ErrorKind values the reference returns
  *   - all arrays are row-major contiguous, f32 / u64 / i64 little-endian host memory unless a
  *     parameter says "device"
+ *   - entry points taking DEVICE pointers run on a library-owned stream created with
+ *     hipStreamDefault, i.e. ordered after work already queued on the legacy null stream (where
+ *     PyTorch-ROCm launches by default); callers using other streams must synchronise first.
+ *     Every entry point returns only after its device work has completed.
  *   - a vi_indexer handle may be shared by several host threads (search is serialised
  *     internally per handle; the reference's search is &self, ivf_index_tests.rs:768-807)
  */
@@ -79,6 +83,20 @@ typedef enum vi_assign_mode {
  * labels: n u64 (Rust usize).  dist_out (optional, n f32): lane-order distance to the label. */
 vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint64_t k, uint64_t seed,
                     vi_assign_mode mode, uint64_t *labels, float *dist_out);
+
+/* Same assignment with DEVICE pointers (X_dev n x d, C_dev k x d, labels_dev n u32) on HIP device
+ * `device`: nothing crosses PCIe.  stats (optional) reports the MFMA filter's kernel time and how
+ * many rows needed the exact-order re-check. */
+typedef struct vi_assign_stats {
+  uint64_t n, k;
+  uint64_t ambiguous_rows; /* rows re-evaluated exactly (VI_ASSIGN_EXACT / brute-force path) */
+  uint32_t used_mfma;      /* 1 when the f32-MFMA filter ran, 0 for the exact-order scan kernel */
+  float ms_total;          /* wall time of the call incl. the exact re-check */
+  float ms_filter;         /* HIP-event time of the MFMA kernel alone */
+} vi_assign_stats;
+vi_status vi_assign_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, const float *C_dev,
+                           uint64_t k, uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev,
+                           vi_assign_stats *stats);
 
 /* replaces run_kmeans_mini_batch(&data,k,max_iters,early_stop_threshold,seed)
  * — src/kmeans.rs:64-70.  early_stop_threshold < 0 means None (=> 1e-4).

@@ -162,3 +162,40 @@ def test_index_build_writes_the_same_files_as_the_oracle(n, d, nlist, tmp_path):
     Dg, Ig = gpu.search_sync(Q, 5, 50)
     assert (Ig == Io).all() and (bits(Dg) == bits(Do)).all()
     assert (Ig[:, 0] == ext[: len(Q)].astype(np.int64)).all()
+
+
+@pytest.mark.parametrize("n,d,k,kind", [(5000, 128, 300, "gauss"), (3000, 64, 130, "gauss"), (2000, 100, 256, "gauss"),
+                                        (4000, 7, 500, "gauss"), (3000, 128, 1024, "sift"), (2500, 96, 200, "offset"),
+                                        (2000, 32, 128, "dups"), (1500, 128, 640, "grid")])
+def test_mfma_filtered_exact_assign_equals_brute_force(n, d, k, kind):
+    """VI_ASSIGN_EXACT with k >= 128, d <= 128 runs the f32-MFMA filter (-2 X C^T + |c|^2) with a
+    rigorous error margin and re-checks undecided rows in exact order: labels must equal
+    assign_points_brute_force (kmeans.rs:462-470) on easy, near-tied and exactly tied inputs."""
+    rng = np.random.default_rng(n + 7 * k)
+    if kind == "gauss":
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Cn = X[rng.choice(n, k, replace=False)] + 0.05 * rng.standard_normal((k, d)).astype(np.float32)
+    elif kind == "sift":
+        X = np.clip(np.round(np.abs(rng.standard_normal((n, d)) * 40 + 20)), 0, 218).astype(np.float32)
+        Cn = X[rng.choice(n, k, replace=False)].copy()
+    elif kind == "offset":  # large common offset: tiny relative gaps => most rows need the exact re-check
+        X = (1000.0 + rng.standard_normal((n, d))).astype(np.float32)
+        Cn = (1000.0 + rng.standard_normal((k, d))).astype(np.float32)
+    elif kind == "dups":    # duplicate centroids: exact ties, lowest index must win
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        base = X[rng.choice(n, k // 2, replace=False)]
+        Cn = np.concatenate([base, base])[rng.permutation(k)].copy()
+    else:                   # integer grid: many exact ties between different centroids
+        X = rng.integers(-2, 3, size=(n, d)).astype(np.float32)
+        Cn = rng.integers(-2, 3, size=(k, d)).astype(np.float32)
+    lab_o = O.assign(X, Cn, mode="brute")
+    lab_g = vip.assign(X, Cn, mode=vip.VI_ASSIGN_EXACT)
+    assert (lab_g == lab_o).all(), int((lab_g != lab_o).sum())
+
+
+def test_exact_mode_kmeans_and_build_match_oracle_force_brute(tmp_path):
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((6000, 48)).astype(np.float32)
+    rc, Co, lo, ito = O.kmeans_mini_batch(X, 200, 30, seed=42, force_brute=True)
+    Cg, lg, itg = vip.kmeans_mini_batch(X, 200, 30, seed=42, mode=vip.VI_ASSIGN_EXACT)
+    assert rc == 0 and itg == ito and (bits(Cg) == bits(Co)).all() and (lg == lo).all()

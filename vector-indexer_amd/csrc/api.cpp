@@ -158,6 +158,13 @@ vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint
   return vi::assign_points(X, n, d, C, k, seed, opt, labels, dist_out);
 }
 
+vi_status vi_assign_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, const float *C_dev, uint64_t k,
+                           uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev, vi_assign_stats *stats) {
+  if (n == 0) return VI_OK;
+  if (!X_dev || !C_dev || !labels_dev || d == 0 || k == 0) return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_assign_device");
+  return vi::assign_points_device(device, X_dev, n, d, C_dev, k, seed, mode, labels_dev, stats);
+}
+
 vi_status vi_kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
                                uint64_t seed, vi_assign_mode mode, float *C, uint64_t *labels, uint64_t *iters) {
   vi::KMeansOptions opt;

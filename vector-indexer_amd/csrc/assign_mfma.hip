@@ -1,0 +1,285 @@
+// assign_mfma.hip — exact nearest-centroid assignment with an f32-MFMA filter.
+//
+// Reference semantics: assign_points_brute_force / find_nearest_centroid (src/kmeans.rs:355-373,
+// 462-470): label = arg-min over ALL centroids of compute_distance_simd, strict '<' (lowest index wins).
+//
+// N x k x D is GEMM shaped, so the bulk runs on the matrix cores as  m(i,c) = ||c||^2 - 2 x_i.c
+// (v_mfma_f32_32x32x2_f32, exact f32 products, 157 TF = the f32 vector peak but 2 flops per
+// (i,c,d) instead of the 3 VALU ops of the exact-order chain, and the VALU stays free for the
+// arg-min epilogue).  m differs from the reference's lane-ordered sum only by rounding, and that
+// difference is BOUNDED:
+//
+//   |m(i,c) + ||x_i||^2 - Dist(i,c)| <= E_i   = (D+2) u' (||x_i||^2 + 2 max_c ||c||^2)      (fma chain of D+1 terms + norm rounding)
+//   |d_ref(i,c) - Dist(i,c)|         <= G_i   = (D/8+8) u' 2 (||x_i||^2 + max_c ||c||^2)   (reference's own rounding)
+//   u' = 2^-24 * 1.01
+//
+// A row whose best and second-best m are further apart than 2(E_i + G_i) has a provably unique
+// reference arg-min and keeps the MFMA label; every other row ("ambiguous": near ties, exact ties,
+// duplicate centroids, NaNs) is re-evaluated by the exact-order scan kernel over all centroids.
+// Labels are therefore bit-identical to assign_points_brute_force for every input.
+//
+// Tiling (per workgroup = 4 waves, 256 points; per wave 64 points x 64 centroids per step):
+//   B operand = X^T : each wave keeps its 64 points' D <= 128 dims in REGISTERS for the whole sweep
+//                     (2 x 16 float4 = 128 VGPRs, pre-scaled by -2), so X is read from HBM once;
+//   A operand = C   : 64-centroid tiles streamed through LDS (double buffered, 132-float row
+//                     stride => conflict-free ds_read_b128), shared by the 4 waves;
+//   D             : D[centroid][point] - the point sits on the lane, the 16 accumulator registers are
+//                     16 centroids, so the running (best, second best, arg) update is lane-local:
+//                     v_cmp + v_cndmask + v_med3 + v_min per candidate, no cross-lane traffic until
+//                     the two lane halves are merged once at the very end;
+//   accumulators are initialised with ||c||^2 (no extra K step).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "assign_mfma.hpp"
+
+namespace vi {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileC = 64;          // centroids per LDS tile
+constexpr int kRowStride = 132;     // floats per LDS row (528 B: conflict-free b128 reads)
+constexpr int kTileFloats = kTileC * kRowStride + kTileC;  // rows + norms
+
+__global__ void centroid_norm_kernel(const float *C, uint32_t k, uint32_t d, float *cn) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  double s = 0.0;
+  for (uint32_t j = 0; j < d; ++j) { const double v = C[(size_t)c * d + j]; s += v * v; }
+  cn[c] = (float)s;
+}
+
+struct MfmaArgs {
+  const float *X;
+  uint32_t n, dim;
+  const float *C, *cn;
+  uint32_t k;
+  float margin_scale_x, margin_const;  // margin_i = margin_scale_x * ||x_i||^2 + margin_const
+  uint32_t *label, *amb_list, *namb;
+};
+
+__device__ __forceinline__ void stage_tile(float *buf, const float *C, const float *cn, uint32_t k, uint32_t dim,
+                                           uint32_t tile, int dpad) {
+  // 64 rows x dpad floats, zero padded; rows >= k get +inf norm so they never win
+  const uint32_t row0 = tile * kTileC;
+  const int nvec = dpad / 4;
+  for (int idx = threadIdx.x; idx < kTileC * nvec; idx += 256) {
+    const int r = idx / nvec, c4 = idx - r * nvec;
+    const uint32_t row = row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < k) {
+      const float *src = C + (size_t)row * dim + c4 * 4;
+      if ((dim & 3) == 0) {
+        if ((uint32_t)(c4 * 4) < dim) v = *reinterpret_cast<const float4 *>(src);
+      } else {
+        const uint32_t e = c4 * 4;
+        if (e + 0 < dim) v.x = src[0];
+        if (e + 1 < dim) v.y = src[1];
+        if (e + 2 < dim) v.z = src[2];
+        if (e + 3 < dim) v.w = src[3];
+      }
+    }
+    *reinterpret_cast<float4 *>(buf + r * kRowStride + c4 * 4) = v;
+  }
+  if (threadIdx.x < kTileC) {
+    const uint32_t row = row0 + threadIdx.x;
+    buf[kTileC * kRowStride + threadIdx.x] = row < k ? cn[row] : INFINITY;
+  }
+}
+
+template <int NG, int NP>  // dims padded to 8*NG (NG <= 16); NP x 32 points per wave
+__global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t pbase = blockIdx.x * (128 * NP) + wave * (32 * NP);
+  constexpr int dpad = NG * 8;
+
+  // ---- this wave's 64 points -> B fragments in registers, scaled by -2 (exact) ----
+  float4 xf[NP][NG];
+  float xnv[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    xnv[p] = 0.0f;
+    const uint32_t pt = pbase + p * 32 + j;
+    const bool live = pt < a.n;
+    const float *row = a.X + (size_t)(live ? pt : 0) * a.dim;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const uint32_t e = 8 * g + 4 * h;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        if ((a.dim & 3) == 0) {
+          if (e < a.dim) v = *reinterpret_cast<const float4 *>(row + e);
+        } else {
+          if (e + 0 < a.dim) v.x = row[e + 0];
+          if (e + 1 < a.dim) v.y = row[e + 1];
+          if (e + 2 < a.dim) v.z = row[e + 2];
+          if (e + 3 < a.dim) v.w = row[e + 3];
+        }
+      }
+      xnv[p] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      xf[p][g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+    }
+  }
+  float b1[NP], b2[NP];
+  uint32_t code[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { b1[p] = INFINITY; b2[p] = INFINITY; code[p] = 0u; }
+
+  const uint32_t ntiles = (a.k + kTileC - 1) / kTileC;
+  stage_tile(lds, a.C, a.cn, a.k, a.dim, 0, dpad);
+  __syncthreads();
+  for (uint32_t ct = 0; ct < ntiles; ++ct) {
+    float *cur = lds + (ct & 1) * kTileFloats;
+    if (ct + 1 < ntiles) stage_tile(lds + ((ct + 1) & 1) * kTileFloats, a.C, a.cn, a.k, a.dim, ct + 1, dpad);
+
+    // accumulators start at ||c||^2 of their centroid row: rows 8*q + 4*h + (0..3) for regs 4q..4q+3
+    f32x16 acc[NP][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 nn = *reinterpret_cast<const float4 *>(cur + kTileC * kRowStride + rt * 32 + 8 * q + 4 * h);
+        acc[0][rt][4 * q + 0] = nn.x; acc[0][rt][4 * q + 1] = nn.y;
+        acc[0][rt][4 * q + 2] = nn.z; acc[0][rt][4 * q + 3] = nn.w;
+      }
+#pragma unroll
+    for (int p = 1; p < NP; ++p) { acc[p][0] = acc[0][0]; acc[p][1] = acc[0][1]; }
+
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      // A fragments: centroid row j (and 32 + j), dims 8g + 4h .. +3 — the same k permutation as xf
+      const float4 a0 = *reinterpret_cast<const float4 *>(cur + j * kRowStride + 8 * g + 4 * h);
+      const float4 a1 = *reinterpret_cast<const float4 *>(cur + (32 + j) * kRowStride + 8 * g + 4 * h);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const float bv = t == 0 ? xf[p][g].x : t == 1 ? xf[p][g].y : t == 2 ? xf[p][g].z : xf[p][g].w;
+          acc[p][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv, acc[p][0], 0, 0, 0);
+          acc[p][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[t], bv, acc[p][1], 0, 0, 0);
+        }
+      }
+    }
+
+    // lane-local running best / second best / code (code = tile*32 + rt*16 + reg)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[p][rt][r];
+          const uint32_t cd = ct * 32 + rt * 16 + r;
+          code[p] = v < b1[p] ? cd : code[p];
+          b2[p] = __builtin_amdgcn_fmed3f(b1[p], b2[p], v);
+          b1[p] = fminf(b1[p], v);
+        }
+    __syncthreads();  // everyone is done with `cur`, and the next tile is staged
+  }
+
+  // ---- merge the two lane halves (same point, disjoint centroid rows) ----
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t cd = code[p];
+    const uint32_t r = cd & 15, rt = (cd >> 4) & 1, ct = cd >> 5;
+    uint32_t cen = ct * kTileC + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float ob1 = __shfl_xor(b1[p], 32), ob2 = __shfl_xor(b2[p], 32);
+    const uint32_t ocen = (uint32_t)__shfl_xor((int)cen, 32);
+    const float x2 = xnv[p];
+    const float xnt = x2 + __shfl_xor(x2, 32);
+    const float nb1 = fminf(b1[p], ob1);
+    const float nb2 = fminf(fmaxf(b1[p], ob1), fminf(b2[p], ob2));
+    if (ob1 < b1[p] || (ob1 == b1[p] && ocen < cen)) cen = ocen;
+    const uint32_t pt = pbase + p * 32 + j;
+    if (h == 0 && pt < a.n) {
+      const float margin = a.margin_scale_x * xnt + a.margin_const;
+      const bool sure = (nb2 - nb1) > margin;  // false for NaN / inf-inf
+      a.label[pt] = cen < a.k ? cen : 0u;
+      if (!sure) a.amb_list[atomicAdd(a.namb, 1u)] = pt;
+    }
+  }
+}
+
+template <int NG, int NP>
+vi_status launch_mfma(const MfmaArgs &a, hipStream_t st) {
+  const size_t smem = 2 * kTileFloats * sizeof(float);
+  VI_HIP(hipFuncSetAttribute((const void *)mfma_assign_kernel<NG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)smem));
+  constexpr uint32_t ppb = 128 * NP;  // points per workgroup
+  hipLaunchKernelGGL((mfma_assign_kernel<NG, NP>), dim3((a.n + ppb - 1) / ppb), dim3(256), smem, st, a);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
+}  // namespace
+
+bool mfma_assign_supported(uint64_t n, uint64_t k, uint32_t d) {
+  return d >= 1 && d <= 128 && k >= 128 && n >= 1 && k < (1ull << 26);
+}
+
+vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint64_t k, uint32_t d,
+                             uint32_t *labels_dev, MfmaAssignWs &ws, hipStream_t st, ExactRowsFn exact, void *exact_ctx,
+                             MfmaAssignStats *stats) {
+  VI_TRY(ws.cn.reserve(k));
+  VI_TRY(ws.namb.reserve(1));
+  hipLaunchKernelGGL(centroid_norm_kernel, dim3((uint32_t)((k + 255) / 256)), dim3(256), 0, st, Cd, (uint32_t)k, d,
+                     ws.cn.p);
+  VI_HIP(hipGetLastError());
+  std::vector<float> h_cn(k);
+  VI_HIP(hipMemcpyAsync(h_cn.data(), ws.cn.p, k * 4, hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
+  double cmax = 0.0;
+  for (uint64_t c = 0; c < k; ++c) cmax = std::max(cmax, (double)h_cn[c]);
+  // margin_i = 2 (E_i + G_i), see the file header; computed in double, rounded up
+  const double u = 1.01 * std::ldexp(1.0, -24);
+  const double e = (d + 2.0) * u, g = (d / 8.0 + 8.0) * u * 2.0;
+  MfmaArgs a{};
+  a.X = Xd; a.dim = d; a.C = Cd; a.cn = ws.cn.p; a.k = (uint32_t)k;
+  a.margin_scale_x = (float)(2.0 * (e + g) * 1.0001);
+  a.margin_const = (float)(2.0 * (2.0 * e + g) * cmax * 1.0001);
+  a.namb = ws.namb.p;
+  const int ng = (int)((d + 7) / 8);
+  uint64_t total_amb = 0;
+  float ms_filter = 0.0f;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (stats) { VI_HIP(hipEventCreate(&ev0)); VI_HIP(hipEventCreate(&ev1)); }
+  const uint64_t chunk = 1ull << 24;  // points per launch (bounds the ambiguous list)
+  VI_TRY(ws.amb_list.reserve(std::min(chunk, n)));
+  for (uint64_t p0 = 0; p0 < n; p0 += chunk) {
+    const uint64_t m = std::min(chunk, n - p0);
+    VI_HIP(hipMemsetAsync(ws.namb.p, 0, sizeof(uint32_t), st));
+    a.X = Xd + p0 * d; a.n = (uint32_t)m; a.label = labels_dev + p0; a.amb_list = ws.amb_list.p;
+    if (stats) VI_HIP(hipEventRecord(ev0, st));
+    if (ng <= 4) VI_TRY((launch_mfma<4, 2>(a, st)));
+    else if (ng <= 8) VI_TRY((launch_mfma<8, 2>(a, st)));
+    else if (ng <= 12) VI_TRY((launch_mfma<12, 1>(a, st)));
+    else VI_TRY((launch_mfma<16, 1>(a, st)));  // 128 dims: 2 x 32 points would not fit 256 VGPRs
+    if (stats) VI_HIP(hipEventRecord(ev1, st));
+    uint32_t namb = 0;
+    VI_HIP(hipMemcpyAsync(&namb, ws.namb.p, 4, hipMemcpyDeviceToHost, st));
+    VI_HIP(hipStreamSynchronize(st));
+    if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1); ms_filter += ms; }
+    if (namb) {
+      // exact-order re-evaluation of the ambiguous rows over ALL centroids
+      VI_TRY(exact(exact_ctx, Xd + p0 * d, ws.amb_list.p, namb, labels_dev + p0));
+    }
+    total_amb += namb;
+  }
+  if (stats) {
+    stats->ambiguous_rows = total_amb;
+    stats->ms_filter = ms_filter;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
+  return VI_OK;
+}
+
+}  // namespace vi

@@ -1,0 +1,33 @@
+// assign_mfma.hpp — exact nearest-centroid assignment with an f32-MFMA filter (assign_mfma.hip).
+#pragma once
+#include <cstdint>
+
+#include "common.hpp"
+
+namespace vi {
+
+struct MfmaAssignStats {
+  uint64_t ambiguous_rows = 0;  // rows re-evaluated by the exact-order scan
+  float ms_filter = 0.0f;       // HIP-event time of the MFMA kernel launches
+};
+
+struct MfmaAssignWs {
+  DevBuf<float> cn;
+  DevBuf<uint32_t> namb, amb_list;
+};
+
+// Re-evaluates rows rows_dev[0..nrows) of X (row-major, device) exactly over all centroids and
+// writes labels[rows_dev[i]].  Provided by the caller (kmeans.hip: exact-order scan kernel).
+typedef vi_status (*ExactRowsFn)(void *ctx, const float *X, const uint32_t *rows_dev, uint32_t nrows,
+                                 uint32_t *labels);
+
+// d <= 128 and k >= 128: the shapes the register-resident X tile covers
+bool mfma_assign_supported(uint64_t n, uint64_t k, uint32_t d);
+
+// labels_dev[i] = arg-min_c compute_distance_simd(X_i, C_c) with strict '<' — bit-identical to
+// assign_points_brute_force (src/kmeans.rs:462-470).  All pointers are device pointers.
+vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint64_t k, uint32_t d,
+                             uint32_t *labels_dev, MfmaAssignWs &ws, hipStream_t st, ExactRowsFn exact, void *exact_ctx,
+                             MfmaAssignStats *stats);
+
+}  // namespace vi

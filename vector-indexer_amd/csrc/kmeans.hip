@@ -19,10 +19,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
 
+#include "assign_mfma.hpp"
 #include "device_index.hpp"
 #include "device_math.hpp"
 #include "kmeans.hpp"
@@ -129,6 +131,11 @@ __global__ void label_dist_kernel(const float *X, const float *C, const uint32_t
   out[i] = l2sq_lanes_dev(X + i * d, C + (size_t)label[i] * d, d);
 }
 
+__global__ void scatter_labels_kernel(const uint32_t *rows, const uint32_t *vals, uint32_t n, uint32_t *labels) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) labels[rows[i]] = vals[i];
+}
+
 __global__ void i64_to_u32_kernel(const int64_t *in, uint64_t n, uint32_t *out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i] < 0 ? 0u : (uint32_t)in[i];
@@ -148,7 +155,7 @@ struct Ctx {
     if (dev < 0 || dev >= ndev) return fail(VI_ERR_DEVICE, "device %d out of range (%d visible)", dev, ndev);
     device = dev;
     VI_HIP(hipSetDevice(dev));
-    VI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    VI_HIP(hipStreamCreateWithFlags(&st, hipStreamDefault));
     return VI_OK;
   }
 };
@@ -276,11 +283,49 @@ vi_status assign_hier_device(Ctx &cx, const float *Xd, uint64_t n, const float *
   return VI_OK;
 }
 
+// exact re-evaluation of the rows the MFMA filter could not decide (assign_mfma.hpp: ExactRowsFn)
+struct ExactCtx {
+  Ctx *cx;
+  const float *Cd;
+  uint64_t k;
+  uint32_t d;
+  BruteWs *bws;
+  DevBuf<float> rows;
+  DevBuf<uint32_t> labels;
+};
+
+vi_status exact_rows_cb(void *vctx, const float *X, const uint32_t *rows_dev, uint32_t nrows, uint32_t *labels) {
+  ExactCtx &e = *static_cast<ExactCtx *>(vctx);
+  VI_TRY(e.rows.reserve((uint64_t)nrows * e.d));
+  VI_TRY(e.labels.reserve(nrows));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows), dim3(64), 0, e.cx->st, X, rows_dev, nrows, e.d, e.rows.p);
+  VI_HIP(hipGetLastError());
+  VI_TRY(assign_brute_device(*e.cx, e.rows.p, nrows, e.Cd, e.k, e.d, e.labels.p, nullptr, *e.bws));
+  hipLaunchKernelGGL(scatter_labels_kernel, dim3((nrows + 255) / 256), dim3(256), 0, e.cx->st, rows_dev, e.labels.p,
+                     nrows, labels);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipStreamSynchronize(e.cx->st));
+  return VI_OK;
+}
+
+// exact brute-force assignment: MFMA filter + exact re-check where the shape allows, else the
+// exact-order scan kernel alone.  Both give assign_points_brute_force's labels bit for bit.
+vi_status assign_exact_device(Ctx &cx, const float *Xd, uint64_t n, const float *Cd, uint64_t k, uint32_t d,
+                              uint32_t *labels_dev, BruteWs &bws, MfmaAssignStats *stats = nullptr) {
+  const char *off = getenv("VI_NO_MFMA");
+  if (mfma_assign_supported(n, k, d) && !(off && *off == '1')) {
+    MfmaAssignWs mws;
+    ExactCtx ectx{&cx, Cd, k, d, &bws, {}, {}};
+    return mfma_assign_device(Xd, n, Cd, k, d, labels_dev, mws, cx.st, exact_rows_cb, &ectx, stats);
+  }
+  return assign_brute_device(cx, Xd, n, Cd, k, d, labels_dev, nullptr, bws);
+}
+
 // assign_points_simd_parallel (kmeans.rs:445-459)
 vi_status assign_device(Ctx &cx, const float *Xd, uint64_t n, const float *Cd, uint64_t k, uint32_t d, uint64_t seed,
                         vi_assign_mode mode, uint32_t *labels_dev, BruteWs &bws) {
   if (mode == VI_ASSIGN_REFERENCE && k > 100) return assign_hier_device(cx, Xd, n, Cd, k, d, seed, labels_dev);
-  return assign_brute_device(cx, Xd, n, Cd, k, d, labels_dev, nullptr, bws);
+  return assign_exact_device(cx, Xd, n, Cd, k, d, labels_dev, bws);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -406,6 +451,36 @@ vi_status assign_points(const float *X, uint64_t n, uint32_t d, const float *C, 
   return labels_to_host(cx, lab.p, n, labels);
 }
 
+vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t d, const float *Cd, uint64_t k,
+                               uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev, vi_assign_stats *stats) {
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  BruteWs bws;
+  hipEvent_t e0, e1;
+  VI_HIP(hipEventCreate(&e0));
+  VI_HIP(hipEventCreate(&e1));
+  VI_HIP(hipEventRecord(e0, cx.st));
+  MfmaAssignStats ms;
+  vi_status rc;
+  const bool hier = mode == VI_ASSIGN_REFERENCE && k > 100;
+  if (hier) rc = assign_hier_device(cx, Xd, n, Cd, k, d, seed, labels_dev);
+  else rc = assign_exact_device(cx, Xd, n, Cd, k, d, labels_dev, bws, &ms);
+  if (rc == VI_OK) {
+    VI_HIP(hipEventRecord(e1, cx.st));
+    VI_HIP(hipStreamSynchronize(cx.st));
+    if (stats) {
+      stats->n = n; stats->k = k;
+      stats->ambiguous_rows = ms.ambiguous_rows;
+      stats->ms_filter = ms.ms_filter;
+      stats->used_mfma = (!hier && ms.ms_filter > 0.0f) ? 1u : 0u;
+      (void)hipEventElapsedTime(&stats->ms_total, e0, e1);
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
 vi_status kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
                           uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run) {
   if (thr < 0) thr = 1e-4f;  // unwrap_or(1e-4), kmeans.rs:22
@@ -484,7 +559,7 @@ vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, 
     hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)B), dim3(64), 0, cx.st, Xd.p, d_bidx.p, (uint32_t)B, d, Qb.p);
     VI_HIP(hipGetLastError());
     // batch assignment is always brute force over all k (kmeans.rs:103-110)
-    VI_TRY(assign_brute_device(cx, Qb.p, B, Cd.p, k, d, d_blab.p, nullptr, bws));
+    VI_TRY(assign_exact_device(cx, Qb.p, B, Cd.p, k, d, d_blab.p, bws));
     VI_HIP(hipMemcpyAsync(blab.data(), d_blab.p, B * 4, hipMemcpyDeviceToHost, cx.st));
     VI_HIP(hipStreamSynchronize(cx.st));
     // group the batch by cluster, batch order inside a cluster (kmeans.rs:739-742)

@@ -15,6 +15,8 @@ struct KMeansOptions {
 
 vi_status assign_points(const float *X, uint64_t n, uint32_t d, const float *C, uint64_t k, uint64_t seed,
                         const KMeansOptions &opt, uint64_t *labels, float *dist_out);
+vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t d, const float *Cd, uint64_t k,
+                               uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev, vi_assign_stats *stats);
 vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
                             uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run);
 vi_status kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,

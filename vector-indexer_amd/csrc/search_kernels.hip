@@ -904,7 +904,7 @@ static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, ui
   ix->dim = dim;
   ix->dq = layout_dq(dim);
   ix->nlists = nlists;
-  if (!ix->stream) VI_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  if (!ix->stream) VI_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamDefault));
   for (auto &e : ix->ev)
     if (!e) VI_HIP(hipEventCreate(&e));
   return VI_OK;

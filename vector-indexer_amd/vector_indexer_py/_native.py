@@ -37,6 +37,11 @@ class SearchStats(C.Structure):
                 ("ms_group", f32), ("ms_scan", f32), ("ms_merge", f32)]
 
 
+class AssignStats(C.Structure):
+    _fields_ = [("n", u64), ("k", u64), ("ambiguous_rows", u64), ("used_mfma", u32), ("ms_total", f32),
+                ("ms_filter", f32)]
+
+
 SIGNATURES = {
     "vi_last_error": (C.c_char_p, []),
     "vi_abi_version": (u32, []),
@@ -46,6 +51,7 @@ SIGNATURES = {
     "vi_minibatch_size": (u64, [u64]),
     "vi_l2sq_pairs": (C.c_int, [vp, vp, u64, u32, C.c_int, vp]),
     "vi_assign": (C.c_int, [vp, u64, u32, vp, u64, u64, C.c_int, vp, vp]),
+    "vi_assign_device": (C.c_int, [i32, vp, u64, u32, vp, u64, u64, C.c_int, vp, vp]),
     "vi_kmeans_mini_batch": (C.c_int, [vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
     "vi_kmeans_parallel": (C.c_int, [vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
     "vi_shard_save_to": (C.c_int, [C.c_char_p, u64, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
