@@ -63,33 +63,44 @@ struct MfmaArgs {
   uint32_t *label, *amb_list, *namb;
 };
 
-__device__ __forceinline__ void stage_tile(float *buf, const float *C, const float *cn, uint32_t k, uint32_t dim,
-                                           uint32_t tile, int dpad) {
-  // 64 rows x dpad floats, zero padded; rows >= k get +inf norm so they never win
+// C tile staging, split in two halves (issue-early / write-late): the global loads of tile t+1 are
+// issued before the MFMAs of tile t and land in LDS after them, so their latency is hidden.
+// dim % 4 == 0 is required (mfma_assign_supported); columns >= dim are zero, rows >= k get a +inf
+// norm so they never win.
+template <int NG>
+struct TileRegs {
+  static constexpr int kNvec = 2 * NG;                 // float4 per row
+  static constexpr int kPerThread = kTileC * kNvec / 256;
+  float4 v[kPerThread];
+  float norm;
+};
+
+template <int NG>
+__device__ __forceinline__ void tile_load(TileRegs<NG> &t, const float *C, const float *cn, uint32_t k, uint32_t dim,
+                                          uint32_t tile) {
   const uint32_t row0 = tile * kTileC;
-  const int nvec = dpad / 4;
-  for (int idx = threadIdx.x; idx < kTileC * nvec; idx += 256) {
-    const int r = idx / nvec, c4 = idx - r * nvec;
+#pragma unroll
+  for (int i = 0; i < TileRegs<NG>::kPerThread; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int r = idx / TileRegs<NG>::kNvec, c4 = idx % TileRegs<NG>::kNvec;
     const uint32_t row = row0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < k) {
-      const float *src = C + (size_t)row * dim + c4 * 4;
-      if ((dim & 3) == 0) {
-        if ((uint32_t)(c4 * 4) < dim) v = *reinterpret_cast<const float4 *>(src);
-      } else {
-        const uint32_t e = c4 * 4;
-        if (e + 0 < dim) v.x = src[0];
-        if (e + 1 < dim) v.y = src[1];
-        if (e + 2 < dim) v.z = src[2];
-        if (e + 3 < dim) v.w = src[3];
-      }
-    }
-    *reinterpret_cast<float4 *>(buf + r * kRowStride + c4 * 4) = v;
+    t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < k && (uint32_t)(c4 * 4) < dim)
+      t.v[i] = *reinterpret_cast<const float4 *>(C + (size_t)row * dim + c4 * 4);
   }
-  if (threadIdx.x < kTileC) {
-    const uint32_t row = row0 + threadIdx.x;
-    buf[kTileC * kRowStride + threadIdx.x] = row < k ? cn[row] : INFINITY;
+  t.norm = INFINITY;
+  if (threadIdx.x < kTileC && row0 + threadIdx.x < k) t.norm = cn[row0 + threadIdx.x];
+}
+
+template <int NG>
+__device__ __forceinline__ void tile_write(const TileRegs<NG> &t, float *buf) {
+#pragma unroll
+  for (int i = 0; i < TileRegs<NG>::kPerThread; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int r = idx / TileRegs<NG>::kNvec, c4 = idx % TileRegs<NG>::kNvec;
+    *reinterpret_cast<float4 *>(buf + r * kRowStride + c4 * 4) = t.v[i];
   }
+  if (threadIdx.x < kTileC) buf[kTileC * kRowStride + threadIdx.x] = t.norm;
 }
 
 template <int NG, int NP>  // dims padded to 8*NG (NG <= 16); NP x 32 points per wave
@@ -98,7 +109,6 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const uint32_t pbase = blockIdx.x * (128 * NP) + wave * (32 * NP);
-  constexpr int dpad = NG * 8;
 
   // ---- this wave's 64 points -> B fragments in registers, scaled by -2 (exact) ----
   float4 xf[NP][NG];
@@ -113,16 +123,7 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
     for (int g = 0; g < NG; ++g) {
       const uint32_t e = 8 * g + 4 * h;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live) {
-        if ((a.dim & 3) == 0) {
-          if (e < a.dim) v = *reinterpret_cast<const float4 *>(row + e);
-        } else {
-          if (e + 0 < a.dim) v.x = row[e + 0];
-          if (e + 1 < a.dim) v.y = row[e + 1];
-          if (e + 2 < a.dim) v.z = row[e + 2];
-          if (e + 3 < a.dim) v.w = row[e + 3];
-        }
-      }
+      if (live && e < a.dim) v = *reinterpret_cast<const float4 *>(row + e);
       xnv[p] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
       xf[p][g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
     }
@@ -133,11 +134,14 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
   for (int p = 0; p < NP; ++p) { b1[p] = INFINITY; b2[p] = INFINITY; code[p] = 0u; }
 
   const uint32_t ntiles = (a.k + kTileC - 1) / kTileC;
-  stage_tile(lds, a.C, a.cn, a.k, a.dim, 0, dpad);
+  TileRegs<NG> stage;
+  tile_load<NG>(stage, a.C, a.cn, a.k, a.dim, 0);
+  tile_write<NG>(stage, lds);
   __syncthreads();
   for (uint32_t ct = 0; ct < ntiles; ++ct) {
     float *cur = lds + (ct & 1) * kTileFloats;
-    if (ct + 1 < ntiles) stage_tile(lds + ((ct + 1) & 1) * kTileFloats, a.C, a.cn, a.k, a.dim, ct + 1, dpad);
+    const bool more = ct + 1 < ntiles;
+    if (more) tile_load<NG>(stage, a.C, a.cn, a.k, a.dim, ct + 1);  // in flight during this tile's MFMAs
 
     // accumulators start at ||c||^2 of their centroid row: rows 8*q + 4*h + (0..3) for regs 4q..4q+3
     f32x16 acc[NP][2];
@@ -182,6 +186,7 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
           b2[p] = __builtin_amdgcn_fmed3f(b1[p], b2[p], v);
           b1[p] = fminf(b1[p], v);
         }
+    if (more) tile_write<NG>(stage, lds + ((ct + 1) & 1) * kTileFloats);  // that buffer was last read before the previous barrier
     __syncthreads();  // everyone is done with `cur`, and the next tile is staged
   }
 
@@ -222,7 +227,7 @@ vi_status launch_mfma(const MfmaArgs &a, hipStream_t st) {
 }  // namespace
 
 bool mfma_assign_supported(uint64_t n, uint64_t k, uint32_t d) {
-  return d >= 1 && d <= 128 && k >= 128 && n >= 1 && k < (1ull << 26);
+  return d >= 4 && d <= 128 && (d % 4) == 0 && k >= 128 && n >= 1 && k < (1ull << 26);
 }
 
 vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint64_t k, uint32_t d,
@@ -259,7 +264,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     a.X = Xd + p0 * d; a.n = (uint32_t)m; a.label = labels_dev + p0; a.amb_list = ws.amb_list.p;
     if (stats) VI_HIP(hipEventRecord(ev0, st));
     if (ng <= 4) VI_TRY((launch_mfma<4, 2>(a, st)));
-    else if (ng <= 8) VI_TRY((launch_mfma<8, 2>(a, st)));
+    else if (ng <= 8) VI_TRY((launch_mfma<8, 1>(a, st)));
     else if (ng <= 12) VI_TRY((launch_mfma<12, 1>(a, st)));
     else VI_TRY((launch_mfma<16, 1>(a, st)));  // 128 dims: 2 x 32 points would not fit 256 VGPRs
     if (stats) VI_HIP(hipEventRecord(ev1, st));
