@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--nprobe", type=int, default=0, help="0 = smallest of the sweep with recall@10 >= 0.95")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kmeans", action="store_true")
+    ap.add_argument("--assign-n", type=int, default=10_000_000)
     ap.add_argument("--work-dir", default=None)
     args = ap.parse_args()
 
@@ -174,7 +176,7 @@ def main():
     gt = ground_truth(xb, xq, k)
     sweep = {}
     chosen = args.nprobe
-    for p in [1, 2, 4, 8, 16, 32, 64]:
+    for p in ([] if chosen else [1, 2, 4, 8, 16, 32, 64]):
         r1, ri = recalls(step(p), gt)
         sweep[p] = {"recall_1nn_at_k": round(r1, 4), "recall_at_k": round(ri, 4)}
         if not chosen and ri >= 0.95:
@@ -221,6 +223,48 @@ def main():
                 "note": "achieved counts 4*D+8 B per (query, scanned vector); a list block loaded once is reused by "
                         "up to 8 queries from registers, so the algorithmic rate can exceed what crosses HBM"}
 
+    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
+    # this same command; gfx950 correction applied as MI355X_MICROARCH.md prescribes) when they match this workload
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_scan_traffic.json")) as f:
+            tr = json.load(f)
+        if tr["workload"] == [args.n, args.d, args.nlist, chosen, nq, k] and world == 1:
+            roofline["traffic"] = tr["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
+    except Exception:
+        pass
+
+    # ---- second BASELINE metric: k-means assign on the matrix cores (config C3) ---------------------------
+    kmeans = None
+    if rank == 0 and world == 1 and not args.no_kmeans:
+        import ctypes as C
+        del xb
+        torch.cuda.empty_cache()
+        n3, d3, k3 = args.assign_n, 128, 16384
+        g = torch.Generator(device=device); g.manual_seed(42)
+        X3 = torch.randn(n3, d3, generator=g, device=device)
+        C3 = X3[torch.randperm(n3, generator=g, device=device)[:k3]].contiguous()
+        lab = torch.empty(n3, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        ast = _native.AssignStats()
+        best = None
+        for _ in range(2):
+            _native.check(_native.lib().vi_assign_device(local_rank, X3.data_ptr(), n3, d3, C3.data_ptr(), k3, 42, 1,
+                                                         lab.data_ptr(), C.byref(ast)))
+            if best is None or ast.ms_total < best[0]:
+                best = (ast.ms_total, ast.ms_filter, int(ast.ambiguous_rows))
+        flops = 2.0 * n3 * k3 * d3
+        tf = flops / (best[1] * 1e-3) / 1e12
+        kmeans = {"workload": f"exact nearest-centroid assign N={n3} D={d3} k={k3} (BASELINE config C3), one full pass",
+                  "ms_total": round(best[0], 2), "ms_mfma_filter": round(best[1], 2), "ambiguous_rows_rechecked": best[2],
+                  "roofline": {"kernel": "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                               "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                               "flops_per_launch": flops},
+                  "hbm_GBps": round((4.0 * n3 * d3 + 4.0 * n3) / (best[1] * 1e-3) / 1e9, 1),
+                  "note": "labels are bit-identical to assign_points_brute_force: rows whose MFMA margin is not "
+                          "provably safe are re-evaluated in the reference's exact summation order"}
+        del X3, C3, lab
+
     # ---- CPU baseline: the oracle (C restatement of the reference's CPU path) on the host cores -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -252,7 +296,7 @@ def main():
                           "nprobe_sweep": sweep, "index_centroids": index.num_centroids, "build_s": round(build_s, 1),
                           "parallelism": f"lists sharded over {world} GPU(s), coarse table replicated"
                                          + (", RCCL all-gather of per-rank top-k" if world > 1 else "")},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "kmeans_assign": kmeans}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

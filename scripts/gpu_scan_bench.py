@@ -40,16 +40,11 @@ def run(label, n_probe, reps=6, **env):
     m = {f: round(float(np.mean(v)), 3) for f, v in acc.items()}
     lane_ops = st["scanned_vectors"] * d * 3
     print(f"{label:34s} nprobe={n_probe:3d} {m} items={st['scan_items']} pairs={nq * n_probe} "
-          f"scanned/q={st['scanned_vectors'] / nq:.0f} valu_frac={lane_ops / (m['ms_scan'] * 1e-3) / 78.6e12:.3f}", flush=True)
+          f"scanned/q={st['scanned_vectors'] / nq:.0f} valu_frac={lane_ops / (m['ms_scan'] * 1e-3) / 78.6e12:.3f} "
+          f"tile_blocks={st['filter_tile_blocks']} fill={st['scanned_vectors'] / max(1, st['filter_tile_blocks'] * 2048):.2f} "
+          f"rechecked={st['filter_rechecked']} accepted={st['filter_accepted']} fallback={st['fallback_queries']}", flush=True)
 
 
 for p in (16, 32):
-    run("default", p)
-    run("seg off", p, VI_SEG_BLOCKS=100000)
-    run("seg 64", p, VI_SEG_BLOCKS=64)
-    run("seg 32", p, VI_SEG_BLOCKS=32)
-    run("seg off, no select", p, VI_SEG_BLOCKS=100000, VI_NO_SELECT=1)
-    run("seg 16, no select", p, VI_NO_SELECT=1)
-    run("seg off, qg4", p, VI_SEG_BLOCKS=100000, VI_FORCE_QG=4)
-    run("seg off, qg4, no select", p, VI_SEG_BLOCKS=100000, VI_FORCE_QG=4, VI_NO_SELECT=1)
-    run("seg off, qg1", p, VI_SEG_BLOCKS=100000, VI_FORCE_QG=1)
+    run("filter", p)
+    run("valu", p, VI_FILTER=0)

@@ -200,3 +200,44 @@ def test_generic_path_equals_fast_path(tmp_path, monkeypatch):
         for qi in (0, 57):
             for j in range(min(k, 5)):
                 assert gen[2][qi, j].tobytes() == X[np.nonzero(np.arange(len(X)) == gen[1][qi, j])[0][0]].tobytes()
+
+
+@pytest.mark.parametrize("n,d,nlist,kind", [(20000, 64, 0, "gauss"), (6000, 128, 24, "gauss"), (4000, 96, 0, "gauss"),
+                                            (5000, 32, 12, "clustered"), (3000, 8, 40, "grid"), (9000, 100, 30, "sift")])
+def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
+    """VI_FILTER=1 forces the f32-MFMA filter + exact re-check pipeline (filter_search.hip).  Its result must be
+    the oracle's, bit for bit, including ties, short lists (bound = inf -> exact pipeline) and overflowing
+    candidate lists (many duplicates -> exact pipeline)."""
+    rng = np.random.default_rng(n + d)
+    if kind == "gauss":
+        X = rng.standard_normal((n, d)).astype(np.float32)
+    elif kind == "clustered":
+        centers = rng.standard_normal((8, d)).astype(np.float32) * 5
+        X = (centers[rng.integers(0, 8, n)] + 0.2 * rng.standard_normal((n, d))).astype(np.float32)
+    elif kind == "grid":
+        X = rng.integers(-2, 3, size=(n, d)).astype(np.float32)      # masses of exact ties / duplicates
+    else:
+        X = np.clip(np.round(np.abs(rng.standard_normal((n, d)) * 40 + 20)), 0, 218).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    Q = np.concatenate([X[:100], (X[100:400] + 0.01 * rng.standard_normal((300, d))).astype(np.float32),
+                        rng.standard_normal((100, d)).astype(np.float32) * float(np.abs(X).mean() + 1)])
+    monkeypatch.setenv("VI_FILTER", "1")
+    for k, n_probe in [(10, 8), (1, 1), (64, 16), (10, 64), (5, 3)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+    check_parity(orc, gpu, Q[:3], 10, 4)
+    st = gpu.last_stats()
+    assert st["nq"] == 3
+    monkeypatch.setenv("VI_FILTER", "0")
+    check_parity(orc, gpu, Q, 10, 8)
+
+
+def test_mfma_filter_candidate_overflow_falls_back(tmp_path, monkeypatch):
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((4, 16)).astype(np.float32)
+    X = np.repeat(base, 5000, axis=0)                                  # 5000 exact copies of each vector (> 4096 slots)
+    X = X[rng.permutation(len(X))]
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=4)
+    Q = np.concatenate([base, rng.standard_normal((60, 16)).astype(np.float32)])
+    monkeypatch.setenv("VI_FILTER", "1")
+    check_parity(orc, gpu, Q, 10, 4)
+    assert gpu.last_stats()["fallback_queries"] > 0

@@ -57,6 +57,10 @@ struct SearchWorkspace {
   DevBuf<uint64_t> stats;       // device-side counters
   DevBuf<float> V;
   // generic (large k / n_probe) path
+  // MFMA filter path (filter_search.hip)
+  DevBuf<uint32_t> probes0, cand_cnt, cand_key;
+  DevBuf<float> tau, cand_dist;
+  DevBuf<uint8_t> fallback;
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };
@@ -74,6 +78,8 @@ struct DeviceIndex {
   DevBuf<uint32_t> list_len;          // [nlists]  (0 => not resident here / empty)
   DevBuf<uint32_t> list_shard;        // [nlists]
   DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
+  DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (+inf on pad slots)
+  float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   mutable std::mutex mu;              // one search at a time per handle
@@ -99,6 +105,8 @@ struct SearchIO {
   uint64_t *counts = nullptr;      // host only
 };
 vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io);
+// squared norms of the stored vectors (filter_search.hip); called at the end of every index upload
+vi_status compute_slot_norms(DeviceIndex *ix);
 
 // Build a device index from device-resident arrays (used by the k-means path, where the
 // "index" is the two-level centroid hierarchy of assign_points_hierarchical, kmeans.rs:474-581,

@@ -30,7 +30,7 @@ struct ScanArgs {
   // longer than the others; segment runs of one (query, list) pair go to seg_run_* at
   // (segrun_start[list] + pair_in_list * nseg + seg) and are merged by seg_merge_kernel
   uint32_t segb0;
-  uint32_t no_select;  // experiment knob: replace top-k selection by a running min (wrong results)
+  uint32_t max_blocks;  // 0 = whole list; else only the first max_blocks blocks are scanned (bound sampling)
   // dump mode (generic_search.hip): instead of selecting, write one key per candidate,
   // (dist bits << 32) | index, at dump_keys[row * dump_row + index]; COARSE: row = query,
   // index = centroid; LISTS: row = slot / P, index = dump_off[slot] + position in list

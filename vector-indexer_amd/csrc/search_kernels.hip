@@ -31,6 +31,7 @@
 #include "device_index.hpp"
 #include "device_math.hpp"
 #include "scan.hpp"
+#include "wave_select.hpp"
 
 namespace vi {
 namespace {
@@ -40,79 +41,14 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
 // Minimum blocks (x64 vectors) per list segment.  Measured on the C2 workload (profiles/
 // r01_experiments.md): cutting lists finer than this costs more in repeated top-k warm-up than it
-// gains in load balance, so only extreme lists (> 16k vectors) are cut.
-constexpr uint32_t kSegBlocksDefault = 256;
+// gains in load balance, so only extreme lists (> 64k vectors) are cut (seg 256 measured +9 %).
+constexpr uint32_t kSegBlocksDefault = 1024;
 
 // tuning knobs for experiments (scripts/gpu_scan_bench.py); unset => defaults
 inline uint32_t env_u32(const char *name, uint32_t dflt) {
   const char *v = getenv(name);
   return (v && *v) ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
-
-// ------------------------------------------------------------------------------------------
-// wave primitives
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
-// value of lane-1 (DPP wave_shr:1); lane 0 receives `fill`
-__device__ __forceinline__ float shr1_f(float v, float fill) {
-  return __int_as_float(
-      __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ uint32_t shr1_u(uint32_t v, uint32_t fill) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
-    const uint64_t t = ((uint64_t)hi << 32) | lo;
-    v = t < v ? t : v;
-  }
-  return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-resident sorted top-K (K <= 64): lane i holds the i-th best (dist, pos) pair in
-// ascending (dist, pos) order.  `thr`/`thrp` cache entry K-1 (wave-uniform).
-// ------------------------------------------------------------------------------------------
-struct WaveTopK {
-  float d;
-  uint32_t p;
-  float thr;
-  uint32_t thrp;
-  __device__ __forceinline__ void init() {
-    d = INFINITY; p = kNoPos; thr = INFINITY; thrp = kNoPos;
-  }
-  // Offer one candidate per lane (dist, pos); pos == kNoPos marks an invalid lane.
-  // Candidates beat entry K-1 iff (dist,pos) < (thr,thrp) lexicographically.
-  __device__ __forceinline__ void offer(float dist, uint32_t pos, int K) {
-    bool pass = (dist < thr) || (dist == thr && pos < thrp);
-    uint64_t mask = __ballot(pass);
-    while (mask) {
-      const int src = __builtin_ctzll(mask);
-      const float cd = readlane_f(dist, src);
-      const uint32_t cp = readlane_u(pos, src);
-      // entries greater than the candidate shift one lane to the right
-      const bool gt = (d > cd) || (d == cd && p > cp);
-      const float ud = shr1_f(d, -INFINITY);
-      const uint32_t up = shr1_u(p, 0u);
-      const bool ugt = (ud > cd) || (ud == cd && up > cp);
-      d = gt ? (ugt ? ud : cd) : d;
-      p = gt ? (ugt ? up : cp) : p;
-      thr = readlane_f(d, K - 1);
-      thrp = readlane_u(p, K - 1);
-      pass = (dist < thr) || (dist == thr && pos < thrp);
-      const uint64_t rest = (src == 63) ? 0ull : (~0ull << (src + 1));
-      mask = __ballot(pass) & rest;
-    }
-  }
-};
 
 // ------------------------------------------------------------------------------------------
 // Exact-order accumulators.  SCALAR: src/utils.rs:28-30.  LANES: src/kmeans.rs:377-419
@@ -181,7 +117,7 @@ struct Acc<VI_ORDER_LANES, QG> {
 // ------------------------------------------------------------------------------------------
 // scan kernel
 // ------------------------------------------------------------------------------------------
-template <int QG, int ORDER, bool COARSE>
+template <int QG, int ORDER, bool COARSE, bool DUMP>
 __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & (kWave - 1);
@@ -235,6 +171,7 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
     const uint32_t nblk = (len + kWave - 1) / kWave;
     b0 = seg * segb;
     b1 = min(nblk, b0 + segb);
+    if (a.max_blocks) b1 = min(b1, a.max_blocks);
   }
 
   // stage the group's queries in this wave's LDS slice, zero padded to dq*4 floats
@@ -295,14 +232,12 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
       for (int j = 0; j < QG; ++j)
         if (j < (int)nqi) {
           const float dj = valid ? acc.finish(j) : INFINITY;
-          if (a.dump_keys) {  // generic path: every candidate is written out, nothing is selected
+          if (DUMP) {  // generic path: every candidate is written out, nothing is selected
             if (valid) {
               const uint32_t idx = COARSE ? pos : a.dump_off[slot[j]] + pos;
               const uint64_t row = COARSE ? (uint64_t)qid[j] : (uint64_t)(slot[j] / a.P);
               a.dump_keys[row * a.dump_row + idx] = ((uint64_t)__float_as_uint(dj) << 32) | idx;
             }
-          } else if (a.no_select) {
-            sel[j].d = fminf(sel[j].d, dj);  // experiment knob: cost of selection
           } else {
             sel[j].offer(dj, p, K);
           }
@@ -313,7 +248,7 @@ __global__ void __launch_bounds__(kBlockThreads) scan_kernel(ScanArgs a) {
     }
   }
 
-  if (lane < K && !a.dump_keys) {
+  if (!DUMP && lane < K) {
 #pragma unroll
     for (int j = 0; j < QG; ++j)
       if (j < (int)nqi) {
@@ -455,7 +390,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   uint32_t seg = 0, item = 0, run = 0;
-  unsigned long long vec = 0;
+  unsigned long long vec = 0, tb = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint32_t c = cnt[l];
     uint32_t segb;
@@ -464,7 +399,9 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     item += ((c + qg - 1) / qg) * ns;
     run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * list_len[l];
+    tb += (unsigned long long)((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
   }
+  atomicAdd((unsigned long long *)&stats[3], tb);
   s_seg[t] = seg; s_item[t] = item; s_run[t] = run; s_vec[t] = vec;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -699,15 +636,15 @@ __global__ void l2sq_pairs_kernel(const float *a, const float *b, uint64_t n, ui
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
-template <int QG, int ORDER, bool COARSE>
+template <int QG, int ORDER, bool COARSE, bool DUMP>
 vi_status launch_scan_t(const ScanArgs &a, uint32_t nitems_upper, hipStream_t st) {
   if (nitems_upper == 0) return VI_OK;
   const uint32_t grid = (nitems_upper + kWavesPerBlock - 1) / kWavesPerBlock;
   const size_t smem = (size_t)kWavesPerBlock * QG * a.dq * sizeof(float4);
   if (smem > 64 * 1024)
-    VI_HIP(hipFuncSetAttribute((const void *)scan_kernel<QG, ORDER, COARSE>,
+    VI_HIP(hipFuncSetAttribute((const void *)scan_kernel<QG, ORDER, COARSE, DUMP>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((scan_kernel<QG, ORDER, COARSE>), dim3(grid), dim3(kBlockThreads), smem, st, a);
+  hipLaunchKernelGGL((scan_kernel<QG, ORDER, COARSE, DUMP>), dim3(grid), dim3(kBlockThreads), smem, st, a);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -728,15 +665,24 @@ int pick_qg(uint32_t dq, double avg_queries_per_unit, int order) {
 }
 
 vi_status launch_scan(const ScanArgs &a, int qg, int order, bool coarse, uint32_t nitems_upper, hipStream_t st) {
-#define VI_SCAN_CASE(QGV)                                                                               \
-  if (qg == QGV) {                                                                                      \
-    if (order == VI_ORDER_SCALAR)                                                                       \
-      return coarse ? launch_scan_t<QGV, VI_ORDER_SCALAR, true>(a, nitems_upper, st)                    \
-                    : launch_scan_t<QGV, VI_ORDER_SCALAR, false>(a, nitems_upper, st);                  \
-    return coarse ? launch_scan_t<(QGV > 4 ? 4 : QGV), VI_ORDER_LANES, true>(a, nitems_upper, st)      \
-                  : launch_scan_t<(QGV > 4 ? 4 : QGV), VI_ORDER_LANES, false>(a, nitems_upper, st);     \
+#define VI_SCAN_CASE(QGV)                                                                                  \
+  if (qg == QGV) {                                                                                         \
+    constexpr int QL = QGV > 4 ? 4 : QGV; /* LANES order keeps 8 accumulators per pair: cap the group */   \
+    if (a.dump_keys) {                                                                                     \
+      if (order == VI_ORDER_SCALAR)                                                                        \
+        return coarse ? launch_scan_t<QGV, VI_ORDER_SCALAR, true, true>(a, nitems_upper, st)               \
+                      : launch_scan_t<QGV, VI_ORDER_SCALAR, false, true>(a, nitems_upper, st);             \
+      return coarse ? launch_scan_t<QL, VI_ORDER_LANES, true, true>(a, nitems_upper, st)                   \
+                    : launch_scan_t<QL, VI_ORDER_LANES, false, true>(a, nitems_upper, st);                 \
+    }                                                                                                      \
+    if (order == VI_ORDER_SCALAR)                                                                          \
+      return coarse ? launch_scan_t<QGV, VI_ORDER_SCALAR, true, false>(a, nitems_upper, st)                \
+                    : launch_scan_t<QGV, VI_ORDER_SCALAR, false, false>(a, nitems_upper, st);              \
+    return coarse ? launch_scan_t<QL, VI_ORDER_LANES, true, false>(a, nitems_upper, st)                    \
+                  : launch_scan_t<QL, VI_ORDER_LANES, false, false>(a, nitems_upper, st);                  \
   }
   VI_SCAN_CASE(1)
+  VI_SCAN_CASE(2)
   VI_SCAN_CASE(4)
   VI_SCAN_CASE(8)
 #undef VI_SCAN_CASE
@@ -891,7 +837,7 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
     VI_HIP(hipMemcpy(ix->list_len.p, h_len.data(), k * 4, hipMemcpyHostToDevice));
     VI_HIP(hipMemcpy(ix->list_shard.p, h_shard.data(), k * 4, hipMemcpyHostToDevice));
   }
-  return VI_OK;
+  return compute_slot_norms(ix);
 }
 
 static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists) {
@@ -970,12 +916,130 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
     VI_HIP(hipMemcpy(ix->list_len.p, h_len.data(), nlists * 4, hipMemcpyHostToDevice));
     VI_HIP(hipMemcpy(ix->list_shard.p, h_shard.data(), nlists * 4, hipMemcpyHostToDevice));
   }
-  return VI_OK;
+  return compute_slot_norms(ix);
 }
+
+vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
+                                 float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
+                                 bool timing);
+bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint32_t P);
 
 vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
                                       float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
                                       hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// pipeline stages
+// ------------------------------------------------------------------------------------------
+// 1+2: coarse scan over the centroid table, merge -> ws.probes / ws.gorder, histogram in ws.cnt
+vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
+  SearchWorkspace &ws = ix.ws;
+  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint64_t nlists = ix.nlists;
+  VI_TRY(ws.cnt.reserve(2 * nlists));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
+  const int qg_c = pick_qg(dq, (double)nq, ix.order);
+  const uint32_t nqg = (uint32_t)((nq + qg_c - 1) / qg_c);
+  uint32_t bps = 0;
+  const uint32_t S = coarse_splits(nq, qg_c, nblk_c, &bps);
+  VI_TRY(ws.crun_dist.reserve(nq * S * P));
+  VI_TRY(ws.crun_pos.reserve(nq * S * P));
+  {
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
+    a.K = P; a.run_dist = ws.crun_dist.p; a.run_pos = ws.crun_pos.p;
+    a.nvec = (uint32_t)nlists; a.S = S; a.bps = bps;
+    VI_TRY(launch_scan(a, qg_c, ix.order, true, nqg * S, st));
+  }
+  VI_TRY(ws.probes.reserve(nq * P));
+  VI_TRY(ws.gorder.reserve(nq * P));
+  CoarseMergeArgs a{ws.crun_dist.p, ws.crun_pos.p, (uint32_t)nq, S, P, ix.list_shard.p, ix.list_len.p,
+                    ws.probes.p, ws.gorder.p, ws.cnt.p};
+  hipLaunchKernelGGL(coarse_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                     dim3(kBlockThreads), 0, st, a);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
+// exact-order VALU pipeline: coarse -> group -> list scan -> final merge
+vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
+                               float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
+                               bool timing) {
+  SearchWorkspace &ws = ix.ws;
+  vi_search_stats &stt = ix.stats;
+  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint64_t nlists = ix.nlists;
+  VI_TRY(ws.run_dist.reserve(nq * P * K));
+  VI_TRY(ws.run_pos.reserve(nq * P * K));
+  // runs of lists that are not resident here (other rank / unreadable shard) stay empty
+  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
+
+  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+  VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
+  // ---- 3. group (query,probe) pairs by list ----
+  const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
+  int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
+  {
+    const uint32_t f = env_u32("VI_FORCE_QG", 0);
+    if (f == 1 || f == 2 || f == 4 || (f == 8 && ix.order == VI_ORDER_SCALAR)) qg_l = (int)f;
+  }
+  const uint32_t kSegBlocks = std::max<uint32_t>(1, env_u32("VI_SEG_BLOCKS", kSegBlocksDefault));
+  VI_TRY(ws.seg_start.reserve(nlists + 1));
+  VI_TRY(ws.item_start.reserve(nlists + 1));
+  VI_TRY(ws.pairs.reserve(nq * P));
+  VI_TRY(ws.segrun_start.reserve(nlists + 1));
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
+                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
+  VI_HIP(hipGetLastError());
+  {
+    const uint32_t total = (uint32_t)(nq * P);
+    hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
+                       ix.list_len.p, ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
+    VI_HIP(hipGetLastError());
+  }
+  // exact work-item / segment-run counts size the scan grid and its scratch
+  uint64_t hstats[3] = {0, 0, 0};
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
+  stt.scanned_vectors = hstats[0];
+  stt.scan_items = hstats[1];
+  const uint64_t nsegruns = hstats[2];
+  VI_TRY(ws.seg_run_dist.reserve(nsegruns * K));
+  VI_TRY(ws.seg_run_pos.reserve(nsegruns * K));
+  if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
+  // ---- 4. list scan ----
+  {
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
+    a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
+    a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
+    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P;
+    a.segb0 = kSegBlocks; a.segrun_start = ws.segrun_start.p;
+    a.seg_run_dist = ws.seg_run_dist.p; a.seg_run_pos = ws.seg_run_pos.p;
+    VI_TRY(launch_scan(a, qg_l, ix.order, false, (uint32_t)hstats[1], st));
+    if (nsegruns) {
+      SegMergeArgs m{ws.seg_start.p, ws.segrun_start.p, ix.list_len.p, ws.pairs.p, (uint32_t)nlists, kSegBlocks, K,
+                     ws.seg_run_dist.p, ws.seg_run_pos.p, ws.run_dist.p, ws.run_pos.p};
+      const uint32_t npairs = (uint32_t)(nq * P);
+      hipLaunchKernelGGL(seg_merge_kernel, dim3((npairs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads),
+                         0, st, m);
+      VI_HIP(hipGetLastError());
+    }
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
+  // ---- 5. final merge ----
+  {
+    FinalMergeArgs a{ws.run_dist.p, ws.run_pos.p, (uint32_t)nq, P, K, (uint32_t)k, ws.probes.p, ws.gorder.p,
+                     ix.list_first_block.p, ix.ext_ids.p, Dd, Id, Td, slots, counts};
+    hipLaunchKernelGGL(final_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                       dim3(kBlockThreads), 0, st, a);
+    VI_HIP(hipGetLastError());
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+  return VI_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // search pipeline (fast path: n_probe_eff <= 64 and k <= 64)
@@ -1030,106 +1094,14 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     return VI_OK;
   }
 
+  const bool use_filter = !generic && filter_path_applicable(ix, nq, k, P);
   const bool timing = ix.timing && !generic;
   if (generic) {
     VI_TRY(device_index_search_generic(ix, Qd, nq, k, P, Dd, Id, Td, slots, ws.counts.p, st));
+  } else if (use_filter) {
+    VI_TRY(search_filter_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing));
   } else {
-  VI_TRY(ws.cnt.reserve(2 * nlists));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
-  VI_TRY(ws.run_dist.reserve(nq * P * K));
-  VI_TRY(ws.run_pos.reserve(nq * P * K));
-  // runs of lists that are not resident here (other rank / unreadable shard) stay empty
-  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
-
-  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
-
-  // ---- 1. coarse scan over the centroid table ----
-  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
-  const int qg_c = pick_qg(dq, (double)nq, ix.order);
-  const uint32_t nqg = (uint32_t)((nq + qg_c - 1) / qg_c);
-  uint32_t bps = 0;
-  const uint32_t S = coarse_splits(nq, qg_c, nblk_c, &bps);
-  VI_TRY(ws.crun_dist.reserve(nq * S * P));
-  VI_TRY(ws.crun_pos.reserve(nq * S * P));
-  {
-    ScanArgs a{};
-    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
-    a.K = P; a.run_dist = ws.crun_dist.p; a.run_pos = ws.crun_pos.p;
-    a.nvec = (uint32_t)nlists; a.S = S; a.bps = bps;
-    VI_TRY(launch_scan(a, qg_c, ix.order, true, nqg * S, st));
-  }
-  // ---- 2. merge -> probes, shard order, histogram ----
-  VI_TRY(ws.probes.reserve(nq * P));
-  VI_TRY(ws.gorder.reserve(nq * P));
-  {
-    CoarseMergeArgs a{ws.crun_dist.p, ws.crun_pos.p, (uint32_t)nq, S, P, ix.list_shard.p, ix.list_len.p,
-                      ws.probes.p, ws.gorder.p, ws.cnt.p};
-    hipLaunchKernelGGL(coarse_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
-                       dim3(kBlockThreads), 0, st, a);
-    VI_HIP(hipGetLastError());
-  }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
-  // ---- 3. group (query,probe) pairs by list ----
-  const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
-  int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
-  {
-    const uint32_t f = env_u32("VI_FORCE_QG", 0);
-    if (f == 1 || f == 4 || (f == 8 && ix.order == VI_ORDER_SCALAR)) qg_l = (int)f;
-  }
-  const uint32_t kSegBlocks = std::max<uint32_t>(1, env_u32("VI_SEG_BLOCKS", kSegBlocksDefault));
-  VI_TRY(ws.seg_start.reserve(nlists + 1));
-  VI_TRY(ws.item_start.reserve(nlists + 1));
-  VI_TRY(ws.pairs.reserve(nq * P));
-  VI_TRY(ws.segrun_start.reserve(nlists + 1));
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
-  VI_HIP(hipGetLastError());
-  {
-    const uint32_t total = (uint32_t)(nq * P);
-    hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
-                       ix.list_len.p, ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
-    VI_HIP(hipGetLastError());
-  }
-  // exact work-item / segment-run counts size the scan grid and its scratch
-  uint64_t hstats[3] = {0, 0, 0};
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
-  stt.scanned_vectors = hstats[0];
-  stt.scan_items = hstats[1];
-  const uint64_t nsegruns = hstats[2];
-  VI_TRY(ws.seg_run_dist.reserve(nsegruns * K));
-  VI_TRY(ws.seg_run_pos.reserve(nsegruns * K));
-  if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
-  // ---- 4. list scan ----
-  {
-    ScanArgs a{};
-    a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
-    a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
-    a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
-    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P;
-    a.segb0 = kSegBlocks; a.segrun_start = ws.segrun_start.p;
-    a.no_select = env_u32("VI_NO_SELECT", 0);
-    a.seg_run_dist = ws.seg_run_dist.p; a.seg_run_pos = ws.seg_run_pos.p;
-    VI_TRY(launch_scan(a, qg_l, ix.order, false, (uint32_t)hstats[1], st));
-    if (nsegruns) {
-      SegMergeArgs m{ws.seg_start.p, ws.segrun_start.p, ix.list_len.p, ws.pairs.p, (uint32_t)nlists, kSegBlocks, K,
-                     ws.seg_run_dist.p, ws.seg_run_pos.p, ws.run_dist.p, ws.run_pos.p};
-      const uint32_t npairs = (uint32_t)(nq * P);
-      hipLaunchKernelGGL(seg_merge_kernel, dim3((npairs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlockThreads),
-                         0, st, m);
-      VI_HIP(hipGetLastError());
-    }
-  }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
-  // ---- 5. final merge ----
-  {
-    FinalMergeArgs a{ws.run_dist.p, ws.run_pos.p, (uint32_t)nq, P, K, (uint32_t)k, ws.probes.p, ws.gorder.p,
-                     ix.list_first_block.p, ix.ext_ids.p, Dd, Id, Td, slots, ws.counts.p};
-    hipLaunchKernelGGL(final_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
-                       dim3(kBlockThreads), 0, st, a);
-    VI_HIP(hipGetLastError());
-  }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+    VI_TRY(search_valu_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing));
   }
 
   // ---- results ----
@@ -1175,6 +1147,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pairs.reserve(total));
   VI_TRY(ws.stats.reserve(8));
   VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
   hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total,
                      ws.cnt.p);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,

@@ -1,0 +1,77 @@
+// wave_select.hpp — wave64 primitives and the wave-resident sorted top-K used by the search kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_index.hpp"
+
+namespace vi {
+
+// ------------------------------------------------------------------------------------------
+// wave primitives
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+// value of lane-1 (DPP wave_shr:1); lane 0 receives `fill`
+__device__ __forceinline__ float shr1_f(float v, float fill) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t shr1_u(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o);
+    const uint64_t t = ((uint64_t)hi << 32) | lo;
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-resident sorted top-K (K <= 64): lane i holds the i-th best (dist, pos) pair in
+// ascending (dist, pos) order.  `thr`/`thrp` cache entry K-1 (wave-uniform).
+// ------------------------------------------------------------------------------------------
+struct WaveTopK {
+  float d;
+  uint32_t p;
+  float thr;
+  uint32_t thrp;
+  __device__ __forceinline__ void init() {
+    d = INFINITY; p = kNoPos; thr = INFINITY; thrp = kNoPos;
+  }
+  // Offer one candidate per lane (dist, pos); pos == kNoPos marks an invalid lane.
+  // Candidates beat entry K-1 iff (dist,pos) < (thr,thrp) lexicographically.
+  __device__ __forceinline__ void offer(float dist, uint32_t pos, int K) {
+    bool pass = (dist < thr) || (dist == thr && pos < thrp);
+    uint64_t mask = __ballot(pass);
+    while (mask) {
+      const int src = __builtin_ctzll(mask);
+      const float cd = readlane_f(dist, src);
+      const uint32_t cp = readlane_u(pos, src);
+      // entries greater than the candidate shift one lane to the right
+      const bool gt = (d > cd) || (d == cd && p > cp);
+      const float ud = shr1_f(d, -INFINITY);
+      const uint32_t up = shr1_u(p, 0u);
+      const bool ugt = (ud > cd) || (ud == cd && up > cp);
+      d = gt ? (ugt ? ud : cd) : d;
+      p = gt ? (ugt ? up : cp) : p;
+      thr = readlane_f(d, K - 1);
+      thrp = readlane_u(p, K - 1);
+      pass = (dist < thr) || (dist == thr && pos < thrp);
+      const uint64_t rest = (src == 63) ? 0ull : (~0ull << (src + 1));
+      mask = __ballot(pass) & rest;
+    }
+  }
+};
+
+
+}  // namespace vi
