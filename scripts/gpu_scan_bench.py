@@ -45,6 +45,8 @@ def run(label, n_probe, reps=6, **env):
           f"rechecked={st['filter_rechecked']} accepted={st['filter_accepted']} fallback={st['fallback_queries']}", flush=True)
 
 
-for p in (16, 32):
-    run("filter", p)
-    run("valu", p, VI_FILTER=0)
+for p in (16,):
+    run("filter segb 64", p)
+    run("filter segb 32", p, VI_FILTER_SEGB=32)
+    run("filter segb 16", p, VI_FILTER_SEGB=16)
+    run("filter segb 128", p, VI_FILTER_SEGB=128)

@@ -233,8 +233,8 @@ def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
 
 def test_mfma_filter_candidate_overflow_falls_back(tmp_path, monkeypatch):
     rng = np.random.default_rng(5)
-    base = rng.standard_normal((4, 16)).astype(np.float32)
-    X = np.repeat(base, 5000, axis=0)                                  # 5000 exact copies of each vector (> 4096 slots)
+    base = rng.standard_normal((3, 16)).astype(np.float32)
+    X = np.repeat(base, 18000, axis=0)                                 # 18000 exact copies of each vector (> 16384 slots)
     X = X[rng.permutation(len(X))]
     orc, gpu = oracle_and_gpu(tmp_path, X, nlist=4)
     Q = np.concatenate([base, rng.standard_normal((60, 16)).astype(np.float32)])

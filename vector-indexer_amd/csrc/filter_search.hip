@@ -52,10 +52,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
-constexpr int kTileQ = 32;              // queries per work item (one MFMA column tile)
+constexpr int kGroupQ = 128;            // queries per work item: 4 waves x one MFMA column tile of 32
 constexpr uint32_t kSampleBlocks = 8;   // blocks of the nearest list sampled for the bound
-constexpr uint32_t kCap = 4096;         // candidate slots per query
-constexpr uint32_t kQueue = 2048 + 64;  // pair queue per wave (one block can emit 32 x 64 pairs)
+constexpr uint32_t kCap = 16384;        // candidate slots per query
+constexpr uint32_t kSampleRanks = 2;    // nearest lists sampled for the bound (<= 4)
 constexpr uint32_t kPosBits = 26;       // candidate key = (probe rank << 26) | position in list
 
 __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, const uint64_t *ext_ids,
@@ -76,17 +76,31 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
   xnorm[s] = out;
 }
 
-__global__ void take_rank0_kernel(const uint32_t *probes, uint32_t nq, uint32_t P, uint32_t *probes0) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < nq) probes0[q] = probes[(size_t)q * P];
+__global__ void take_first_ranks_kernel(const uint32_t *probes, uint32_t nq, uint32_t P, uint32_t R0,
+                                        uint32_t *probes0) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nq * R0) probes0[t] = probes[(size_t)(t / R0) * P + (t % R0)];
 }
 
-__global__ void tau_kernel(const float *run_dist, const uint32_t *run_pos, uint32_t nq, uint32_t K, uint32_t k,
-                           float *tau) {
+// tau_q = k-th smallest exact distance over the union of the query's R0 sampled runs (each sorted, K entries)
+__global__ void tau_kernel(const float *run_dist, const uint32_t *run_pos, uint32_t nq, uint32_t R0, uint32_t K,
+                           uint32_t k, float *tau) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  const size_t o = (size_t)q * K + (k - 1);
-  tau[q] = run_pos[o] == kNoPos ? INFINITY : run_dist[o];
+  uint32_t head[4] = {0, 0, 0, 0};
+  float last = INFINITY;
+  for (uint32_t i = 0; i < k; ++i) {
+    float best = INFINITY;
+    int br = -1;
+    for (uint32_t r = 0; r < R0; ++r) {
+      const size_t o = ((size_t)q * R0 + r) * K + head[r];
+      if (head[r] < K && run_pos[o] != kNoPos && (br < 0 || run_dist[o] < best)) { best = run_dist[o]; br = (int)r; }
+    }
+    if (br < 0) { last = INFINITY; break; }
+    head[br]++;
+    last = best;
+  }
+  tau[q] = last;
 }
 
 struct FilterArgs {
@@ -103,16 +117,55 @@ struct FilterArgs {
   float *cand_dist;
   uint32_t *cand_key;
   unsigned long long *dbg;  // [4]=pairs re-checked, [5]=pairs accepted
+  uint32_t xmode;           // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no compaction, 4 = no barriers
 };
 
-template <int NG>  // NG = dq/2 exactly: the block layout holds 2*NG quads (dims padded to 16); dim % 4 == 0
+// Workgroup = 4 waves = up to 128 queries (4 column tiles of 32) probing ONE list (segment).  Every
+// 64-vector block of the list is staged once per workgroup into LDS as 64 rows of dq*4 floats (row stride
+// 132 floats => conflict-free ds_read_b128 / ds_write_b128) together with the 64 squared norms, and is
+// consumed by all four waves; the next block's global loads are issued before the MFMAs of the current
+// one and written to LDS after them (issue-early / write-late), as in assign_mfma.hip.
+constexpr int kRowStride = 132;
+constexpr int kTileFloats = 64 * kRowStride + 64;
+constexpr uint32_t kQueue = 2048 + 64;  // pair queue per wave (one block can emit 32 x 64 pairs)
+
+// block staging: 64 vectors x 2*NG quads over 256 threads => NG/2 float4 each (+ one norm for threads < 64)
+template <int NG>
+struct StageRegs {
+  static constexpr int kPerThread = (64 * 2 * NG) / 256;  // NG even => integral
+  float4 v[kPerThread];
+  float norm;
+};
+
+template <int NG>
+__device__ __forceinline__ void stage_load(StageRegs<NG> &s, const float4 *src, const float *xn, bool live) {
+#pragma unroll
+  for (int i = 0; i < StageRegs<NG>::kPerThread; ++i) {
+    s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) s.v[i] = src[threadIdx.x + 256 * i];  // idx = quad*64 + vector: fully coalesced
+  }
+  s.norm = INFINITY;
+  if (live && threadIdx.x < 64) s.norm = xn[threadIdx.x];
+}
+
+template <int NG>
+__device__ __forceinline__ void stage_write(const StageRegs<NG> &s, float *tile) {
+#pragma unroll
+  for (int i = 0; i < StageRegs<NG>::kPerThread; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    *reinterpret_cast<float4 *>(tile + (idx & 63) * kRowStride + (idx >> 6) * 4) = s.v[i];
+  }
+  if (threadIdx.x < 64) tile[64 * kRowStride + threadIdx.x] = s.norm;
+}
+
+template <int NG>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
 __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
+  __shared__ float s_tile[kTileFloats];
   __shared__ uint32_t s_queue[4][kQueue];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   uint32_t *queue = s_queue[wave];
-  const uint32_t item = blockIdx.x * 4 + wave;
-  if (item >= a.item_start[a.nlists]) return;
+  const uint32_t item = blockIdx.x;  // grid == number of items
   uint32_t lo = 0, hi = a.nlists;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -125,15 +178,17 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
   const uint32_t nseg = list_segments(len, a.segb0, &segb);
   const uint32_t local = item - a.item_start[l];
   const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
-  const uint32_t j0 = chunk * kTileQ;
-  const uint32_t nqi = min((uint32_t)kTileQ, cnt - j0);
+  const uint32_t j0 = chunk * kGroupQ;
+  const uint32_t nqi = min((uint32_t)kGroupQ, cnt - j0);
   const uint32_t fb = a.first_block[l];
   const uint32_t nblk = (len + kWave - 1) / kWave;
   const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
 
-  // ---- this lane's query (both lane halves hold the same query j) ----
-  const bool qlive = (uint32_t)j < nqi;
-  const uint32_t slot = qlive ? a.pairs[s0 + j0 + j] : 0u;
+  // ---- this lane's query: wave w owns queries 32w .. 32w+31 of the group; both lane halves hold query j ----
+  const uint32_t jq_grp = 32u * wave + (uint32_t)j;
+  const bool qlive = jq_grp < nqi;
+  const bool wave_live = 32u * wave < nqi;  // wave-uniform
+  const uint32_t slot = qlive ? a.pairs[s0 + j0 + jq_grp] : 0u;
   const uint32_t qid = slot / a.P;
   const float *qrow = a.Q + (size_t)qid * a.dim;
   float4 qf[NG];
@@ -196,96 +251,89 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
     }
   };
 
-  // Per block: two row tiles of 32 vectors, each tile = two halves of NG/2 k-groups.  The A fragments
-  // (float4 per lane and k-group, straight from the lane-interleaved blocks) of the NEXT half are loaded
-  // into the other of two register buffers while the current half's 2*NG MFMAs (>= 1024 cycles) run; a
-  // sched_barrier pins those loads in front of the MFMAs (hipcc otherwise sinks them next to their use
-  // and the L2 latency shows).
-  constexpr int NH = NG / 2;  // NG is even
-  auto tile_base = [&](uint32_t blk, uint32_t t) {
-    return a.blocks + ((size_t)(fb + blk) * a.dq) * kWave + 32 * t + j;
-  };
-  auto load_half = [&](const float4 *vb, int half, float4 (&dst)[NH]) {
-#pragma unroll
-    for (int g = 0; g < NH; ++g) dst[g] = vb[(size_t)(2 * (half * NH + g) + h) * kWave];
-  };
-  auto load_norms = [&](uint32_t blk, uint32_t t, float4 (&nn)[4]) {
-    const float *xn = a.xnorm + (size_t)(fb + blk) * kWave + 32 * t + 4 * h;
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) nn[q4] = *reinterpret_cast<const float4 *>(xn + 8 * q4);
-  };
-  auto init_acc = [&](f32x16 &acc, const float4 (&nn)[4]) {
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) live in regs 4*q4 .. 4*q4+3
-      acc[4 * q4 + 0] = nn[q4].x; acc[4 * q4 + 1] = nn[q4].y; acc[4 * q4 + 2] = nn[q4].z; acc[4 * q4 + 3] = nn[q4].w;
-    }
-  };
-  auto mfma_half = [&](f32x16 &acc, const float4 (&buf)[NH], int half) {
-#pragma unroll
-    for (int g = 0; g < NH; ++g) {
-      const float4 qv = qf[half * NH + g];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[g].x, qv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[g].y, qv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[g].z, qv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[g].w, qv.w, acc, 0, 0, 0);
-    }
-  };
-  float4 buf0[NH], buf1[NH], nn[4];
-  if (b0 < b1) { load_norms(b0, 0, nn); load_half(tile_base(b0, 0), 0, buf0); }
+  // ---- block staging: 64 vectors x 2*NG quads, 256 threads => NG/2 float4 each (+ one norm for t < 64) ----
+  StageRegs<NG> stage;
+  stage_load<NG>(stage, a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, b0 < b1);
+  stage_write<NG>(stage, s_tile);
+  __syncthreads();
   for (uint32_t blk = b0; blk < b1; ++blk) {
+    const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
+    // next block: in flight during this block's MFMAs
+    stage_load<NG>(stage, a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave, a.xnorm + (size_t)(fb + blk + 1) * kWave, more);
     uint32_t bits = 0;
+    if (wave_live) {
+      // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
+      // keep the MFMA pipe busy while the other chain's result and the next LDS fragments are in flight
+      f32x16 acc0, acc1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float4 *vb = tile_base(blk, t);
-      f32x16 acc;
-      init_acc(acc, nn);
-      load_half(vb, 1, buf1);                       // second half of this tile
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_half(acc, buf0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const bool more = (t == 0) || (blk + 1 < b1);
-      if (more) {                                   // first half + norms of the next tile
-        const uint32_t nb = t == 0 ? blk : blk + 1, nt = t == 0 ? 1u : 0u;
-        load_norms(nb, nt, nn);
-        load_half(tile_base(nb, nt), 0, buf0);
+      for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) live in regs 4*q4 .. 4*q4+3
+        const float4 n0 = *reinterpret_cast<const float4 *>(s_tile + 64 * kRowStride + 8 * q4 + 4 * h);
+        const float4 n1 = *reinterpret_cast<const float4 *>(s_tile + 64 * kRowStride + 32 + 8 * q4 + 4 * h);
+        acc0[4 * q4 + 0] = n0.x; acc0[4 * q4 + 1] = n0.y; acc0[4 * q4 + 2] = n0.z; acc0[4 * q4 + 3] = n0.w;
+        acc1[4 * q4 + 0] = n1.x; acc1[4 * q4 + 1] = n1.y; acc1[4 * q4 + 2] = n1.z; acc1[4 * q4 + 3] = n1.w;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_half(acc, buf1, 1);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bits |= (acc[r] <= thr ? 1u : 0u) << (16 * t + r);
-    }
-    if (__ballot(bits != 0u) == 0ull) continue;  // nothing survived in this block (the common case)
-    // ---- compact the surviving (query j, vector) pairs of this block into the wave's queue ----
-    const uint32_t mycnt = __popc(bits);
-    uint32_t incl = mycnt;
+      for (int g = 0; g < NG; ++g) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(s_tile + j * kRowStride + 8 * g + 4 * h);
+        const float4 a1 = *reinterpret_cast<const float4 *>(s_tile + (32 + j) * kRowStride + 8 * g + 4 * h);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qf[g].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qf[g].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qf[g].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, qf[g].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, qf[g].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qf[g].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qf[g].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
+      }
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-      if (lane >= o) incl += up;
+      for (int r = 0; r < 16; ++r) {
+        bits |= (acc0[r] <= thr ? 1u : 0u) << r;
+        bits |= (acc1[r] <= thr ? 1u : 0u) << (16 + r);
+      }
     }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t w = qcount + incl - mycnt;
-    uint32_t bb = bits;
-    while (bb) {
-      const uint32_t bpos = (uint32_t)__builtin_ctz(bb);
-      bb &= bb - 1;
-      const uint32_t t = bpos >> 4, r = bpos & 15u;
-      const uint32_t vec = 32u * t + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
-      queue[w++] = (blk << 11) | (vec << 5) | (uint32_t)j;
+    if (!(a.xmode & 2u) && __ballot(bits != 0u) != 0ull) {
+      // ---- compact the surviving (query j, vector) pairs of this block into the wave's queue ----
+      // Survivors are rare (a few lanes per block): visit the lanes that have any, broadcast their 32-bit
+      // row mask, and let lane L < 32 emit the pair of row-bit L at its rank inside the mask.
+      uint64_t lanes = __ballot(bits != 0u);
+      while (lanes) {
+        const int src = __builtin_ctzll(lanes);
+        lanes &= lanes - 1;
+        const uint32_t b = readlane_u(bits, src);
+        const uint32_t n = __popc(b);
+        // Re-checks are deferred to the end of the item (they would otherwise hold the whole workgroup at
+        // the next barrier); only if the queue cannot take these pairs is it drained here.
+        while (qcount + n > kQueue) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          qcount -= kWave;
+          drain(qcount, kWave);
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < 32 && ((b >> lane) & 1u)) {
+          const uint32_t rank = __popc(b & ((1u << lane) - 1u));
+          const uint32_t t = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
+          const uint32_t vec = 32u * t + (r & 3u) + 8u * (r >> 2) + 4u * ((uint32_t)src >> 5);
+          queue[qcount + rank] = (blk << 11) | (vec << 5) | ((uint32_t)src & 31u);
+        }
+        qcount += n;
+      }
     }
-    qcount += total;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    while (qcount >= (uint32_t)kWave) {  // re-check 64 pairs at a time, from the tail of the queue
-      qcount -= kWave;
-      drain(qcount, kWave);
-    }
-    __builtin_amdgcn_wave_barrier();  // queue reads above complete before the next block appends
+    if (!(a.xmode & 4u)) __syncthreads();  // every wave is done reading the tile
+    if (more) stage_write<NG>(stage, s_tile);
+    if (!(a.xmode & 4u)) __syncthreads();  // next tile visible
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  while (qcount >= (uint32_t)kWave) {  // exact re-check, 64 pairs per pass
+    qcount -= kWave;
+    drain(qcount, kWave);
   }
   if (qcount) drain(0, qcount);
 }
+
 
 struct SelectArgs {
   uint32_t nq, P, k, cap;
@@ -305,8 +353,9 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= a.nq) return;
   const uint32_t n = a.cand_cnt[q];
-  const bool fb = !(a.tau[q] < INFINITY) || n > a.cap;
-  if (lane == 0) a.fallback[q] = fb ? 1 : 0;
+  const bool noinf = a.tau[q] < INFINITY;
+  const bool fb = !noinf || n > a.cap;
+  if (lane == 0) a.fallback[q] = !noinf ? 1 : (n > a.cap ? 2 : 0);
   if (fb) return;
   const uint32_t g_of_r = (uint32_t)lane < a.P ? a.gorder[(size_t)q * a.P + lane] : kNoPos;
   WaveTopK sel;
@@ -372,7 +421,7 @@ __global__ void scatter_results_kernel(const uint32_t *ids, uint32_t n, uint32_t
 template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, hipStream_t st) {
   if (nitems == 0) return VI_OK;
-  hipLaunchKernelGGL((filter_kernel<NG>), dim3((nitems + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((filter_kernel<NG>), dim3(nitems), dim3(256), 0, st, a);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -422,34 +471,36 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(stage_coarse(ix, Qd, nq, P, st));
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
 
-  // ---- 1. bound: exact top-k over the first 512 vectors of each query's nearest list ----
-  VI_TRY(ws.probes0.reserve(nq));
+  // ---- 1. bound: exact top-k over the first 512 vectors of each of the query's nearest lists ----
+  const uint32_t R0 = std::min<uint32_t>(kSampleRanks, P);
+  VI_TRY(ws.probes0.reserve(nq * R0));
   VI_TRY(ws.tau.reserve(nq));
-  VI_TRY(ws.run_dist.reserve(nq * K));
-  VI_TRY(ws.run_pos.reserve(nq * K));
-  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * K * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(take_rank0_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p, (uint32_t)nq,
-                     P, ws.probes0.p);
+  VI_TRY(ws.run_dist.reserve(nq * R0 * K));
+  VI_TRY(ws.run_pos.reserve(nq * R0 * K));
+  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * R0 * K * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(take_first_ranks_kernel, dim3((uint32_t)((nq * R0 + 255) / 256)), dim3(256), 0, st, ws.probes.p,
+                     (uint32_t)nq, P, R0, ws.probes0.p);
   VI_HIP(hipGetLastError());
   uint64_t hstats[3];
   {
-    const int qg = pick_qg(dq, (double)nq / (double)std::max<uint64_t>(1, nlists), ix.order);
+    const int qg = pick_qg(dq, (double)nq * R0 / (double)std::max<uint64_t>(1, nlists), ix.order);
     const uint32_t segb0 = 1u << 20;  // never segment here: only the first blocks are read
-    VI_TRY(launch_grouping(ix, ws.probes0.p, nq, 1, qg, segb0, hstats, st));
+    VI_TRY(launch_grouping(ix, ws.probes0.p, nq, R0, qg, segb0, hstats, st));
     ScanArgs a{};
     a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
     a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
-    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = 1;
+    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = R0;
     a.segb0 = segb0; a.segrun_start = ws.segrun_start.p; a.max_blocks = kSampleBlocks;
     VI_TRY(launch_scan(a, qg, ix.order, false, (uint32_t)hstats[1], st));
     hipLaunchKernelGGL(tau_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.run_dist.p, ws.run_pos.p,
-                       (uint32_t)nq, K, (uint32_t)std::min<uint64_t>(k, K), ws.tau.p);
+                       (uint32_t)nq, R0, K, (uint32_t)std::min<uint64_t>(k, K), ws.tau.p);
     VI_HIP(hipGetLastError());
   }
   // ---- 2. group all (query, probe) pairs by list in tiles of 32 queries ----
-  const uint32_t segb0 = 64;  // <= 4096 vectors per work item
-  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kTileQ, segb0, hstats, st));
+  const char *sb = getenv("VI_FILTER_SEGB");
+  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 64u;  // <= 4096 vectors per work item
+  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
@@ -470,6 +521,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.e_scale = (float)((dim + 2.0) * u);
     a.xmax2 = ix.xmax2;
     a.dbg = (unsigned long long *)ws.stats.p;
+    { const char *xm = getenv("VI_FILTER_XMODE"); a.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
     a.cap = kCap; a.cand_cnt = ws.cand_cnt.p; a.cand_dist = ws.cand_dist.p; a.cand_key = ws.cand_key.p;
     const uint32_t nitems = (uint32_t)hstats[1];
     switch (dq / 2) {  // dq is a multiple of 4
@@ -499,8 +551,12 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_HIP(hipMemcpyAsync(hfb.data(), ws.fallback.p, nq, hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));
   std::vector<uint32_t> ids;
+  uint64_t n_inf = 0;
   for (uint64_t q = 0; q < nq; ++q)
-    if (hfb[q]) ids.push_back((uint32_t)q);
+    if (hfb[q]) { ids.push_back((uint32_t)q); n_inf += hfb[q] == 1; }
+  if (getenv("VI_FILTER_VERBOSE"))
+    fprintf(stderr, "[vi] filter fallback: %zu queries (%llu without a finite bound, %llu candidate overflow)\n",
+            ids.size(), (unsigned long long)n_inf, (unsigned long long)(ids.size() - n_inf));
   stt.fallback_queries = ids.size();
   {
     uint64_t dbg[8];

@@ -39,6 +39,9 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
+// (query, probe) pairs are counted / scattered per (list, query & 7): hot lists are probed by thousands of
+// queries of a batch and a single counter per list serialises their atomics
+constexpr uint32_t kSubBins = 8;
 // Minimum blocks (x64 vectors) per list segment.  Measured on the C2 workload (profiles/
 // r01_experiments.md): cutting lists finer than this costs more in repeated top-k warm-up than it
 // gains in load balance, so only extreme lists (> 64k vectors) are cut (seg 256 measured +9 %).
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = live ? mylist : kNoPos;
     a.gorder[(size_t)q * a.P + lane] = live ? g : kNoPos;
-    if (live && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist], 1u);
+    if (live && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
   }
 }
 
@@ -380,10 +383,17 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 //   item_start   Σ ceil(cnt/QG) * nseg      (scan work items)
 //   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
 // stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
+__device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l) {
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t s = 0; s < kSubBins; ++s) c += cnt[l * kSubBins + s];
+  return c;
+}
+
 __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
                                                           uint32_t nlists, uint32_t qg, uint32_t segb0,
                                                           uint32_t *seg_start, uint32_t *item_start,
-                                                          uint32_t *segrun_start, uint64_t *stats) {
+                                                          uint32_t *segrun_start, uint32_t *cursor, uint64_t *stats) {
   __shared__ uint32_t s_seg[1024], s_item[1024], s_run[1024];
   __shared__ unsigned long long s_vec[1024];
   const uint32_t t = threadIdx.x;
@@ -392,7 +402,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   uint32_t seg = 0, item = 0, run = 0;
   unsigned long long vec = 0, tb = 0;
   for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = cnt[l];
+    const uint32_t c = list_count(cnt, l);
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg += c;
@@ -414,10 +424,12 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   }
   uint32_t rs = s_seg[t] - seg, ri = s_item[t] - item, rr = s_run[t] - run;
   for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = cnt[l];
+    const uint32_t c = list_count(cnt, l);
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
+    uint32_t sub = rs;  // each sub-bin scatters into its own slice of the list's segment
+    for (uint32_t s = 0; s < kSubBins; ++s) { cursor[l * kSubBins + s] = sub; sub += cnt[l * kSubBins + s]; }
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
   }
   if (t == 1023) {
@@ -430,21 +442,22 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   }
 }
 
-__global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t n, uint32_t *cnt) {
+__global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t n, uint32_t P,
+                                 uint32_t *cnt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t l = probes[i];
-  if (l != kNoPos && list_len[l] > 0) atomicAdd(&cnt[l], 1u);
+  if (l != kNoPos && list_len[l] > 0) atomicAdd(&cnt[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
 }
 
-__global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, const uint32_t *seg_start,
-                                     uint32_t *cursor, uint32_t *pairs, uint32_t total) {
+__global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t P, uint32_t *cursor,
+                                     uint32_t *pairs, uint32_t total) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint32_t l = probes[i];
   if (l == kNoPos || list_len[l] == 0) return;
-  const uint32_t pos = atomicAdd(&cursor[l], 1u);
-  pairs[seg_start[l] + pos] = i;  // slot id = q*P + rank
+  const uint32_t pos = atomicAdd(&cursor[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
+  pairs[pos] = i;  // slot id = q*P + rank
 }
 
 // ------------------------------------------------------------------------------------------
@@ -936,8 +949,8 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
   SearchWorkspace &ws = ix.ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
-  VI_TRY(ws.cnt.reserve(2 * nlists));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
   const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
   const int qg_c = pick_qg(dq, (double)nq, ix.order);
   const uint32_t nqg = (uint32_t)((nq + qg_c - 1) / qg_c);
@@ -991,12 +1004,13 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_TRY(ws.pairs.reserve(nq * P));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
+                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
+                     ws.cnt.p + nlists * kSubBins, ws.stats.p);
   VI_HIP(hipGetLastError());
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
-                       ix.list_len.p, ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
+                       ix.list_len.p, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
     VI_HIP(hipGetLastError());
   }
   // exact work-item / segment-run counts size the scan grid and its scratch
@@ -1140,20 +1154,21 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   SearchWorkspace &ws = ix.ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
-  VI_TRY(ws.cnt.reserve(2 * nlists));
+  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
   VI_TRY(ws.seg_start.reserve(nlists + 1));
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(total));
   VI_TRY(ws.stats.reserve(8));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, 2 * nlists * sizeof(uint32_t), st));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
-  hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total,
+  hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total, P,
                      ws.cnt.p);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p);
-  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
-                     ws.seg_start.p, ws.cnt.p + nlists, ws.pairs.p, total);
+                     (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
+                     ws.cnt.p + nlists * kSubBins, ws.stats.p);
+  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
+                     ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
   VI_HIP(hipGetLastError());
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));
