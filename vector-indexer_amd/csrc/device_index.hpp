@@ -58,7 +58,7 @@ struct SearchWorkspace {
   DevBuf<float> V;
   // generic (large k / n_probe) path
   // MFMA filter path (filter_search.hip)
-  DevBuf<uint32_t> probes0, cand_cnt, cand_key;
+  DevBuf<uint32_t> probes0, cand_cnt, cand_key, c_seg, c_item, c_pairs;
   DevBuf<float> tau, cand_dist;
   DevBuf<uint8_t> fallback;
   DevBuf<uint64_t> sort_keys, order_keys, total;
@@ -80,6 +80,9 @@ struct DeviceIndex {
   DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
   DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (+inf on pad slots)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
+  DevBuf<float> cent_xnorm;           // same for the coarse table
+  float cent_xmax2 = 0.0f;
+  DevBuf<uint32_t> c_first, c_len;    // the coarse table described as one list
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   mutable std::mutex mu;              // one search at a time per handle

@@ -398,6 +398,57 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   if (a.counts && lane == 0) a.counts[q] = found;
 }
 
+__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+__global__ void coarse_tau_kernel(const float *run_dist, const uint32_t *run_pos, uint32_t nq, uint32_t P, float *tau) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const size_t o = (size_t)q * P + (P - 1);
+  tau[q] = run_pos[o] == kNoPos ? INFINITY : run_dist[o];
+}
+
+struct CoarseSelectArgs {
+  uint32_t nq, P, cap;
+  const uint32_t *cand_cnt, *cand_key, *list_shard, *list_len;
+  const float *cand_dist;
+  uint32_t *probes, *gorder, *cnt, *overflow;
+};
+
+// one wave per query: the P nearest centroids among the filter's survivors, in (distance, centroid index)
+// order (the reference's stable sort, ivf_index.rs:205-220), then shard visiting order + histogram as in
+// coarse_merge_kernel
+__global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= a.nq) return;
+  const uint32_t n = a.cand_cnt[q];
+  if (n > a.cap || n < a.P) {  // cannot happen with a finite bound unless the list overflowed
+    if (lane == 0) atomicAdd(a.overflow, 1u);
+    return;
+  }
+  WaveTopK sel;
+  sel.init();
+  const int K = (int)a.P;
+  for (uint32_t base = 0; base < n; base += kWave) {
+    const uint32_t i = base + lane;
+    const bool live = i < n;
+    const float d = live ? a.cand_dist[(size_t)q * a.cap + i] : INFINITY;
+    const uint32_t key = live ? (a.cand_key[(size_t)q * a.cap + i] & ((1u << kPosBits) - 1u)) : kNoPos;
+    sel.offer(d, key, K);
+  }
+  const uint32_t found = a.P;
+  const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
+  const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
+  if ((uint32_t)lane < a.P) {
+    a.probes[(size_t)q * a.P + lane] = mylist;
+    a.gorder[(size_t)q * a.P + lane] = g;
+    if (a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+  }
+}
+
 __global__ void gather_queries_kernel(const float *Q, const uint32_t *ids, uint32_t n, uint32_t dim, float *out) {
   const uint32_t r = blockIdx.x;
   if (r >= n) return;
@@ -446,6 +497,121 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   float f;
   std::memcpy(&f, &bits, 4);
   ix->xmax2 = f;
+  // the coarse table: pad slots (>= nlists) must never pass the filter
+  const uint64_t cslots = ix->centroids.nblocks * kWave;
+  VI_TRY(ix->cent_xnorm.reserve(std::max<uint64_t>(1, cslots)));
+  VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
+  if (cslots) {
+    hipLaunchKernelGGL(slot_norms_kernel, dim3((uint32_t)((cslots + 255) / 256)), dim3(256), 0, ix->stream,
+                       (const float4 *)ix->centroids.blocks.p, ix->dq, cslots, (const uint64_t *)nullptr,
+                       ix->cent_xnorm.p, mx.p);
+    VI_HIP(hipGetLastError());
+    const uint64_t npad = cslots - ix->nlists;
+    if (npad) {
+      std::vector<float> inf(npad, INFINITY);
+      VI_HIP(hipMemcpyAsync(ix->cent_xnorm.p + ix->nlists, inf.data(), npad * 4, hipMemcpyHostToDevice, ix->stream));
+    }
+  }
+  VI_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
+  VI_HIP(hipStreamSynchronize(ix->stream));
+  std::memcpy(&f, &bits, 4);
+  ix->cent_xmax2 = f;
+  const uint32_t one_first[1] = {0u}, one_len[1] = {(uint32_t)ix->nlists};
+  VI_TRY(ix->c_first.reserve(1));
+  VI_TRY(ix->c_len.reserve(1));
+  VI_HIP(hipMemcpy(ix->c_first.p, one_first, 4, hipMemcpyHostToDevice));
+  VI_HIP(hipMemcpy(ix->c_len.p, one_len, 4, hipMemcpyHostToDevice));
+  return VI_OK;
+}
+
+static vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, hipStream_t st) {
+  switch (dq / 2) {  // dq is a multiple of 4
+    case 2: return launch_filter_t<2>(a, nitems, st);
+    case 4: return launch_filter_t<4>(a, nitems, st);
+    case 6: return launch_filter_t<6>(a, nitems, st);
+    case 8: return launch_filter_t<8>(a, nitems, st);
+    case 10: return launch_filter_t<10>(a, nitems, st);
+    case 12: return launch_filter_t<12>(a, nitems, st);
+    case 14: return launch_filter_t<14>(a, nitems, st);
+    case 16: return launch_filter_t<16>(a, nitems, st);
+    default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
+  }
+}
+
+static void filter_margins(FilterArgs &a, uint32_t dim, float xmax2) {
+  const double u = 1.01 * std::ldexp(1.0, -24);
+  a.gamma2 = (float)(2.0 * (dim + 2.0) * u);
+  a.e_scale = (float)((dim + 2.0) * u);
+  a.xmax2 = xmax2;
+}
+
+// coarse quantizer on the matrix cores: the centroid table is one "list" probed by every query
+vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st,
+                              bool *done) {
+  SearchWorkspace &ws = ix.ws;
+  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint64_t nlists = ix.nlists;
+  *done = false;
+  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+  VI_TRY(ws.probes.reserve(nq * P));
+  VI_TRY(ws.gorder.reserve(nq * P));
+  VI_TRY(ws.tau.reserve(nq));
+  // a. bound: exact top-P over the first 512 centroids of the table
+  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
+  const uint32_t sblk = std::min<uint32_t>(nblk_c, kSampleBlocks);
+  VI_TRY(ws.crun_dist.reserve(nq * P));
+  VI_TRY(ws.crun_pos.reserve(nq * P));
+  {
+    const int qg = pick_qg(dq, (double)nq, ix.order);
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
+    a.K = P; a.run_dist = ws.crun_dist.p; a.run_pos = ws.crun_pos.p;
+    a.nvec = (uint32_t)std::min<uint64_t>(nlists, (uint64_t)sblk * kWave); a.S = 1; a.bps = sblk;
+    VI_TRY(launch_scan(a, qg, ix.order, true, (uint32_t)((nq + qg - 1) / qg), st));
+    hipLaunchKernelGGL(coarse_tau_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.crun_dist.p,
+                       ws.crun_pos.p, (uint32_t)nq, P, ws.tau.p);
+    VI_HIP(hipGetLastError());
+  }
+  // b. one list, every query probes it: groups of 128 queries x segments of 4 blocks
+  const uint32_t segb0 = 4;
+  uint32_t segb;
+  const uint32_t nseg = list_segments((uint32_t)nlists, segb0, &segb);
+  const uint32_t ngroups = (uint32_t)((nq + kGroupQ - 1) / kGroupQ);
+  const uint32_t h_seg[2] = {0u, (uint32_t)nq}, h_item[2] = {0u, ngroups * nseg};
+  VI_TRY(ws.c_seg.reserve(2));
+  VI_TRY(ws.c_item.reserve(2));
+  VI_TRY(ws.c_pairs.reserve(nq));
+  VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
+  VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.c_pairs.p, (uint32_t)nq);
+  // c. filter + exact re-check
+  VI_TRY(ws.cand_cnt.reserve(nq + 1));
+  VI_TRY(ws.cand_dist.reserve(nq * kCap));
+  VI_TRY(ws.cand_key.reserve(nq * kCap));
+  VI_TRY(ws.stats.reserve(8));
+  VI_HIP(hipMemsetAsync(ws.cand_cnt.p, 0, (nq + 1) * sizeof(uint32_t), st));
+  {
+    FilterArgs a{};
+    a.blocks = (const float4 *)ix.centroids.blocks.p; a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
+    a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
+    a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0; a.tau = ws.tau.p;
+    filter_margins(a, dim, ix.cent_xmax2);
+    a.dbg = (unsigned long long *)ws.stats.p;
+    a.cap = kCap; a.cand_cnt = ws.cand_cnt.p; a.cand_dist = ws.cand_dist.p; a.cand_key = ws.cand_key.p;
+    VI_TRY(launch_filter(a, dq, ngroups * nseg, st));
+  }
+  // d. select the P probes, shard order, histogram
+  {
+    CoarseSelectArgs a{(uint32_t)nq, P, kCap, ws.cand_cnt.p, ws.cand_key.p, ix.list_shard.p, ix.list_len.p,
+                       ws.cand_dist.p, ws.probes.p, ws.gorder.p, ws.cnt.p, ws.cand_cnt.p + nq};
+    hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    VI_HIP(hipGetLastError());
+  }
+  uint32_t overflow = 0;
+  VI_HIP(hipMemcpyAsync(&overflow, ws.cand_cnt.p + nq, 4, hipMemcpyDeviceToHost, st));
+  VI_HIP(hipStreamSynchronize(st));
+  *done = overflow == 0;  // otherwise the caller runs the exact VALU coarse step
   return VI_OK;
 }
 
@@ -468,7 +634,12 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
-  VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+  {
+    bool done = false;
+    const char *cf = getenv("VI_COARSE_FILTER");
+    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) VI_TRY(stage_coarse_filter(ix, Qd, nq, P, st, &done));
+    if (!done) VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+  }
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
 
   // ---- 1. bound: exact top-k over the first 512 vectors of each of the query's nearest lists ----
@@ -499,7 +670,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   }
   // ---- 2. group all (query, probe) pairs by list in tiles of 32 queries ----
   const char *sb = getenv("VI_FILTER_SEGB");
-  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 64u;  // <= 4096 vectors per work item
+  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 16u;  // <= 1024 vectors per work item
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
@@ -511,30 +682,16 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.fallback.reserve(nq));
   VI_HIP(hipMemsetAsync(ws.cand_cnt.p, 0, nq * sizeof(uint32_t), st));
   {
-    const double u = 1.01 * std::ldexp(1.0, -24);
     FilterArgs a{};
     a.blocks = (const float4 *)ix.lists.blocks.p; a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
     a.tau = ws.tau.p;
-    a.gamma2 = (float)(2.0 * (dim + 2.0) * u);
-    a.e_scale = (float)((dim + 2.0) * u);
-    a.xmax2 = ix.xmax2;
+    filter_margins(a, dim, ix.xmax2);
     a.dbg = (unsigned long long *)ws.stats.p;
     { const char *xm = getenv("VI_FILTER_XMODE"); a.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
     a.cap = kCap; a.cand_cnt = ws.cand_cnt.p; a.cand_dist = ws.cand_dist.p; a.cand_key = ws.cand_key.p;
-    const uint32_t nitems = (uint32_t)hstats[1];
-    switch (dq / 2) {  // dq is a multiple of 4
-      case 2: VI_TRY(launch_filter_t<2>(a, nitems, st)); break;
-      case 4: VI_TRY(launch_filter_t<4>(a, nitems, st)); break;
-      case 6: VI_TRY(launch_filter_t<6>(a, nitems, st)); break;
-      case 8: VI_TRY(launch_filter_t<8>(a, nitems, st)); break;
-      case 10: VI_TRY(launch_filter_t<10>(a, nitems, st)); break;
-      case 12: VI_TRY(launch_filter_t<12>(a, nitems, st)); break;
-      case 14: VI_TRY(launch_filter_t<14>(a, nitems, st)); break;
-      case 16: VI_TRY(launch_filter_t<16>(a, nitems, st)); break;
-      default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
-    }
+    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----

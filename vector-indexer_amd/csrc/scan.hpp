@@ -13,6 +13,10 @@ namespace vi {
 // the scan kernel always consumes whole groups of 4 quads
 inline uint32_t layout_dq(uint32_t dim) { return ((dim + 15) / 16) * 4; }
 
+// (query, probe) pairs are counted / scattered per (list, query & 7): hot lists are probed by thousands of
+// queries of a batch and a single counter per list would serialise their atomics
+constexpr uint32_t kSubBins = 8;
+
 struct ScanArgs {
   const float4 *blocks;   // lane-interleaved blocks (device_index.hpp)
   uint32_t dq, dim;

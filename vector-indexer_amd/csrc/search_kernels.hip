@@ -39,9 +39,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = kWave * kWavesPerBlock;
-// (query, probe) pairs are counted / scattered per (list, query & 7): hot lists are probed by thousands of
-// queries of a batch and a single counter per list serialises their atomics
-constexpr uint32_t kSubBins = 8;
+
 // Minimum blocks (x64 vectors) per list segment.  Measured on the C2 workload (profiles/
 // r01_experiments.md): cutting lists finer than this costs more in repeated top-k warm-up than it
 // gains in load balance, so only extreme lists (> 64k vectors) are cut (seg 256 measured +9 %).
@@ -353,21 +351,8 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
     }
     ++found;
   }
-  // shard visiting order = first appearance in the probe list; candidate order of probe i is
-  // its rank under the key (first_appearance(shard_i), i)
   const bool live = (uint32_t)lane < found;
-  const uint32_t shard = live ? a.list_shard[mylist] : kNoPos;
-  uint32_t fa = (uint32_t)lane;
-  for (uint32_t i = 0; i < found; ++i) {
-    const uint32_t s = readlane_u(shard, (int)i);
-    if (live && s == shard && i < fa) fa = i;
-  }
-  const uint32_t okey = live ? fa * 64u + (uint32_t)lane : kNoPos;
-  uint32_t g = 0;
-  for (uint32_t i = 0; i < found; ++i) {
-    const uint32_t k2 = readlane_u(okey, (int)i);
-    g += (k2 < okey) ? 1u : 0u;
-  }
+  const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = live ? mylist : kNoPos;
     a.gorder[(size_t)q * a.P + lane] = live ? g : kNoPos;

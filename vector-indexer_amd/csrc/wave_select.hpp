@@ -74,4 +74,25 @@ struct WaveTopK {
 };
 
 
+// Reference candidate order of a query's probes (src/ivf_index.rs:223-262): shards are visited in order of
+// first appearance in the probe list, probes of one shard in rank order.  Lane i < found holds probe i
+// (list id `mylist`); returns the rank g of probe i under the key (first_appearance(shard_i), i).
+__device__ __forceinline__ uint32_t probe_candidate_order(int lane, uint32_t found, uint32_t mylist,
+                                                          const uint32_t *list_shard) {
+  const bool live = (uint32_t)lane < found;
+  const uint32_t shard = live ? list_shard[mylist] : kNoPos;
+  uint32_t fa = (uint32_t)lane;
+  for (uint32_t i = 0; i < found; ++i) {
+    const uint32_t s = readlane_u(shard, (int)i);
+    if (live && s == shard && i < fa) fa = i;
+  }
+  const uint32_t okey = live ? fa * 64u + (uint32_t)lane : kNoPos;
+  uint32_t g = 0;
+  for (uint32_t i = 0; i < found; ++i) {
+    const uint32_t k2 = readlane_u(okey, (int)i);
+    g += (k2 < okey) ? 1u : 0u;
+  }
+  return g;
+}
+
 }  // namespace vi
