@@ -127,7 +127,6 @@ struct FilterArgs {
 // one and written to LDS after them (issue-early / write-late), as in assign_mfma.hip.
 constexpr int kRowStride = 132;
 constexpr int kTileFloats = 64 * kRowStride + 64;
-constexpr uint32_t kQueue = 2048 + 64;  // pair queue per wave (one block can emit 32 x 64 pairs)
 
 // block staging: 64 vectors x 2*NG quads over 256 threads => NG/2 float4 each (+ one norm for threads < 64)
 template <int NG>
@@ -161,10 +160,8 @@ __device__ __forceinline__ void stage_write(const StageRegs<NG> &s, float *tile)
 template <int NG>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
 __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
   __shared__ float s_tile[kTileFloats];
-  __shared__ uint32_t s_queue[4][kQueue];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  uint32_t *queue = s_queue[wave];
   const uint32_t item = blockIdx.x;  // grid == number of items
   uint32_t lo = 0, hi = a.nlists;
   while (hi - lo > 1) {
@@ -210,48 +207,17 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
     thr = (tau * (1.0f + a.gamma2) + a.e_scale * (qn_hi + 2.0f * a.xmax2)) * 1.0001f - qn_lo;
   }
 
-  uint32_t qcount = 0;  // wave-uniform number of queued pairs
-
-  // exact re-check of queue[off .. off+npairs) (npairs <= 64), one lane per (query, vector) pair
-  auto drain = [&](uint32_t off, uint32_t npairs) {
-    const bool active = (uint32_t)lane < npairs;
-    const uint32_t pr = active ? queue[off + lane] : 0u;
-    const uint32_t jq = pr & 31u, v = (pr >> 5) & 63u, blk = pr >> 11;
-    const uint32_t pslot = (uint32_t)__shfl((int)slot, (int)jq);
-    const float ptau = __shfl(tau, (int)jq);
-    const uint32_t pq = pslot / a.P;
-    const float4 *xq = reinterpret_cast<const float4 *>(a.Q + (size_t)pq * a.dim);
-    const float4 *xv = a.blocks + ((size_t)(fb + blk) * a.dq) * kWave + v;
-    float acc = 0.0f;
-    const uint32_t nquad = a.dim >> 2;
-    uint32_t qd = 0;
-    for (; qd + 4 <= nquad; qd += 4) {  // 8 independent 16-byte loads in flight per lane
-      const float4 q0 = xq[qd], q1 = xq[qd + 1], q2 = xq[qd + 2], q3 = xq[qd + 3];
-      const float4 x0 = xv[(size_t)qd * kWave], x1 = xv[(size_t)(qd + 1) * kWave];
-      const float4 x2 = xv[(size_t)(qd + 2) * kWave], x3 = xv[(size_t)(qd + 3) * kWave];
-      sq_add(acc, q0.x, x0.x); sq_add(acc, q0.y, x0.y); sq_add(acc, q0.z, x0.z); sq_add(acc, q0.w, x0.w);
-      sq_add(acc, q1.x, x1.x); sq_add(acc, q1.y, x1.y); sq_add(acc, q1.z, x1.z); sq_add(acc, q1.w, x1.w);
-      sq_add(acc, q2.x, x2.x); sq_add(acc, q2.y, x2.y); sq_add(acc, q2.z, x2.z); sq_add(acc, q2.w, x2.w);
-      sq_add(acc, q3.x, x3.x); sq_add(acc, q3.y, x3.y); sq_add(acc, q3.z, x3.z); sq_add(acc, q3.w, x3.w);
-    }
-    for (; qd < nquad; ++qd) {
-      const float4 qq = xq[qd];
-      const float4 xx = xv[(size_t)qd * kWave];
-      sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
-    }
-    const unsigned long long nacc = __popcll(__ballot(active && acc <= ptau));
-    if (lane == 0) { atomicAdd(&a.dbg[4], (unsigned long long)npairs); atomicAdd(&a.dbg[5], nacc); }
-    if (active && acc <= ptau) {
-      const uint32_t idx = atomicAdd(&a.cand_cnt[pq], 1u);
-      if (idx < a.cap) {
-        const uint32_t r = pslot - pq * a.P;
-        a.cand_dist[(size_t)pq * a.cap + idx] = acc;
-        a.cand_key[(size_t)pq * a.cap + idx] = (r << kPosBits) | (blk * kWave + v);
-      }
+  // survivors are appended straight to their query's candidate list as (m, key): m = ||v||^2 - 2 q.v is the
+  // MFMA value; the select kernel decides which of them need the exact arithmetic
+  const uint32_t rkey = (slot - qid * a.P) << kPosBits;
+  auto emit = [&](float m, uint32_t pos) {
+    const uint32_t idx = atomicAdd(&a.cand_cnt[qid], 1u);
+    if (idx < a.cap) {
+      a.cand_dist[(size_t)qid * a.cap + idx] = m;
+      a.cand_key[(size_t)qid * a.cap + idx] = rkey | pos;
     }
   };
 
-  // ---- block staging: 64 vectors x 2*NG quads, 256 threads => NG/2 float4 each (+ one norm for t < 64) ----
   StageRegs<NG> stage;
   stage_load<NG>(stage, a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, b0 < b1);
   stage_write<NG>(stage, s_tile);
@@ -260,10 +226,8 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
     const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
     // next block: in flight during this block's MFMAs
     stage_load<NG>(stage, a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave, a.xnorm + (size_t)(fb + blk + 1) * kWave, more);
-    uint32_t bits = 0;
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
-      // keep the MFMA pipe busy while the other chain's result and the next LDS fragments are in flight
       f32x16 acc0, acc1;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) live in regs 4*q4 .. 4*q4+3
@@ -285,60 +249,88 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qf[g].w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
       }
+      if (!(a.xmode & 2u)) {
+        const uint32_t pbase = blk * kWave + 4u * (uint32_t)h;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        bits |= (acc0[r] <= thr ? 1u : 0u) << r;
-        bits |= (acc1[r] <= thr ? 1u : 0u) << (16 + r);
-      }
-    }
-    if (!(a.xmode & 2u) && __ballot(bits != 0u) != 0ull) {
-      // ---- compact the surviving (query j, vector) pairs of this block into the wave's queue ----
-      // Survivors are rare (a few lanes per block): visit the lanes that have any, broadcast their 32-bit
-      // row mask, and let lane L < 32 emit the pair of row-bit L at its rank inside the mask.
-      uint64_t lanes = __ballot(bits != 0u);
-      while (lanes) {
-        const int src = __builtin_ctzll(lanes);
-        lanes &= lanes - 1;
-        const uint32_t b = readlane_u(bits, src);
-        const uint32_t n = __popc(b);
-        // Re-checks are deferred to the end of the item (they would otherwise hold the whole workgroup at
-        // the next barrier); only if the queue cannot take these pairs is it drained here.
-        while (qcount + n > kQueue) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          qcount -= kWave;
-          drain(qcount, kWave);
-          __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r) {  // reg r <-> vector row (r&3) + 8*(r>>2) + 4*h of its 32-row tile
+          if (acc0[r] <= thr) emit(acc0[r], pbase + (r & 3) + 8 * (r >> 2));
+          if (acc1[r] <= thr) emit(acc1[r], pbase + 32u + (r & 3) + 8 * (r >> 2));
         }
-        if (lane < 32 && ((b >> lane) & 1u)) {
-          const uint32_t rank = __popc(b & ((1u << lane) - 1u));
-          const uint32_t t = (uint32_t)lane >> 4, r = (uint32_t)lane & 15u;
-          const uint32_t vec = 32u * t + (r & 3u) + 8u * (r >> 2) + 4u * ((uint32_t)src >> 5);
-          queue[qcount + rank] = (blk << 11) | (vec << 5) | ((uint32_t)src & 31u);
-        }
-        qcount += n;
       }
     }
     if (!(a.xmode & 4u)) __syncthreads();  // every wave is done reading the tile
     if (more) stage_write<NG>(stage, s_tile);
     if (!(a.xmode & 4u)) __syncthreads();  // next tile visible
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  while (qcount >= (uint32_t)kWave) {  // exact re-check, 64 pairs per pass
-    qcount -= kWave;
-    drain(qcount, kWave);
-  }
-  if (qcount) drain(0, qcount);
 }
 
 
+// ------------------------------------------------------------------------------------------
+// select: which survivors need the reference's exact arithmetic, and the final top-K
+// ------------------------------------------------------------------------------------------
+// A query's candidate list holds (m, key) with m = ||v||^2 - 2 q.v from the MFMA.  Let m_K be the K-th
+// smallest m.  The K candidates with the smallest m have d_ref <= (m_K + ||q||^2 + E)(1 + gamma), so the K-th
+// smallest d_ref is at most that, and every candidate of the true top-K satisfies
+//     m <= m_K + 2E + 3 gamma (m_K + ||q||^2 + E)                                   (*)
+// Only candidates passing (*) (K plus a handful) are re-evaluated in exact order; the top-K of those exact
+// distances under the reference's stable order is the answer.
+struct SelectCommon {
+  const float *Q;
+  uint32_t dim, dq, cap;
+  const uint32_t *cand_cnt, *cand_key;
+  const float *cand_dist;
+  float gamma, e_scale, xmax2;
+};
+
+// exact distance of one (query row, stored vector) pair, one lane per pair (src/utils.rs:28-30)
+__device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv, uint32_t dim) {
+  const float4 *xq = reinterpret_cast<const float4 *>(qrow);
+  float acc = 0.0f;
+  const uint32_t nquad = dim >> 2;
+  uint32_t qd = 0;
+  for (; qd + 4 <= nquad; qd += 4) {  // 8 independent 16-byte loads in flight per lane
+    const float4 q0 = xq[qd], q1 = xq[qd + 1], q2 = xq[qd + 2], q3 = xq[qd + 3];
+    const float4 x0 = xv[(size_t)qd * kWave], x1 = xv[(size_t)(qd + 1) * kWave];
+    const float4 x2 = xv[(size_t)(qd + 2) * kWave], x3 = xv[(size_t)(qd + 3) * kWave];
+    sq_add(acc, q0.x, x0.x); sq_add(acc, q0.y, x0.y); sq_add(acc, q0.z, x0.z); sq_add(acc, q0.w, x0.w);
+    sq_add(acc, q1.x, x1.x); sq_add(acc, q1.y, x1.y); sq_add(acc, q1.z, x1.z); sq_add(acc, q1.w, x1.w);
+    sq_add(acc, q2.x, x2.x); sq_add(acc, q2.y, x2.y); sq_add(acc, q2.z, x2.z); sq_add(acc, q2.w, x2.w);
+    sq_add(acc, q3.x, x3.x); sq_add(acc, q3.y, x3.y); sq_add(acc, q3.z, x3.z); sq_add(acc, q3.w, x3.w);
+  }
+  for (; qd < nquad; ++qd) {
+    const float4 qq = xq[qd];
+    const float4 xx = xv[(size_t)qd * kWave];
+    sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
+  }
+  return acc;
+}
+
+// stage 1 of the select: threshold (*) on m for query q with n candidates (wave-uniform result)
+__device__ __forceinline__ float select_threshold(const SelectCommon &c, uint32_t q, uint32_t n, uint32_t K, int lane) {
+  WaveTopK s1;
+  s1.init();
+  for (uint32_t base = 0; base < n; base += kWave) {
+    const uint32_t i = base + lane;
+    const bool live = i < n;
+    s1.offer(live ? c.cand_dist[(size_t)q * c.cap + i] : INFINITY, live ? i : kNoPos, (int)K);
+  }
+  if (n < K) return INFINITY;  // fewer candidates than wanted: all of them are results
+  const float mk = readlane_f(s1.d, (int)K - 1);
+  float qn = 0.0f;
+  for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  const float scale = fmaxf(mk + qn, 0.0f) + E;
+  return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+}
+
 struct SelectArgs {
-  uint32_t nq, P, k, cap;
-  const uint32_t *cand_cnt, *cand_key, *probes, *gorder, *first_block;
-  const float *cand_dist, *tau;
+  SelectCommon c;
+  uint32_t nq, P, k;
+  const float4 *blocks;
+  const uint32_t *probes, *gorder, *first_block;
+  const float *tau;
   const uint64_t *ext_ids;
   float *D;
   int64_t *I;
@@ -349,28 +341,55 @@ struct SelectArgs {
 
 // one wave per query: top-k of its candidates in the reference's stable order
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ uint32_t s_pick[4][128];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  const uint32_t n = a.cand_cnt[q];
+  const SelectCommon &c = a.c;
+  const uint32_t n = c.cand_cnt[q];
   const bool noinf = a.tau[q] < INFINITY;
-  const bool fb = !noinf || n > a.cap;
-  if (lane == 0) a.fallback[q] = !noinf ? 1 : (n > a.cap ? 2 : 0);
+  const bool fb = !noinf || n > c.cap;
+  if (lane == 0) a.fallback[q] = !noinf ? 1 : (n > c.cap ? 2 : 0);
   if (fb) return;
   const uint32_t g_of_r = (uint32_t)lane < a.P ? a.gorder[(size_t)q * a.P + lane] : kNoPos;
+  const uint32_t list_of_r = (uint32_t)lane < a.P ? a.probes[(size_t)q * a.P + lane] : 0u;
+  const uint32_t fb_of_r = (uint32_t)lane < a.P && list_of_r != kNoPos ? a.first_block[list_of_r] : 0u;
+  const float thr2 = select_threshold(c, q, n, a.k, lane);
   WaveTopK sel;
   sel.init();
   const int K = (int)a.k;
+  const float *qrow = c.Q + (size_t)q * c.dim;
+  uint32_t *pick = s_pick[wave];
+  uint32_t npick = 0;
+  auto flush = [&](uint32_t off, uint32_t cnt) {  // exact distances of pick[off..off+cnt), one lane each
+    const bool live = (uint32_t)lane < cnt;
+    const uint32_t ck = live ? pick[off + lane] : 0u;
+    const uint32_t r = ck >> kPosBits, pos = ck & ((1u << kPosBits) - 1u);
+    const uint32_t g = (uint32_t)__shfl((int)g_of_r, (int)r);
+    const uint32_t fbk = (uint32_t)__shfl((int)fb_of_r, (int)r);
+    float d = INFINITY;
+    if (live) d = exact_pair(qrow, a.blocks + ((size_t)(fbk + pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
+    sel.offer(d, live ? ((g << kPosBits) | pos) : kNoPos, K);
+  };
   for (uint32_t base = 0; base < n; base += kWave) {
     const uint32_t i = base + lane;
-    const bool live = i < n;
-    const float d = live ? a.cand_dist[(size_t)q * a.cap + i] : INFINITY;
-    const uint32_t ck = live ? a.cand_key[(size_t)q * a.cap + i] : 0u;
-    // cross-lane read outside of any divergent branch: the source lane (probe rank) must be active
-    const uint32_t g = (uint32_t)__shfl((int)g_of_r, (int)(ck >> kPosBits));
-    const uint32_t key = live ? ((g << kPosBits) | (ck & ((1u << kPosBits) - 1u))) : kNoPos;
-    sel.offer(d, key, K);
+    const bool pass = i < n && c.cand_dist[(size_t)q * c.cap + i] <= thr2;
+    const uint64_t m = __ballot(pass);
+    const uint32_t cntp = (uint32_t)__popcll(m);
+    if (npick + cntp > 128) {
+      __builtin_amdgcn_wave_barrier();
+      while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
+      if (npick) { flush(0, npick); npick = 0; }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (pass) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c.cand_key[(size_t)q * c.cap + i];
+    npick += cntp;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
+  if (npick) flush(0, npick);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
   const uint32_t g = sel.p >> kPosBits, pos = sel.p & ((1u << kPosBits) - 1u);
   uint32_t r = 0;
@@ -411,9 +430,10 @@ __global__ void coarse_tau_kernel(const float *run_dist, const uint32_t *run_pos
 }
 
 struct CoarseSelectArgs {
-  uint32_t nq, P, cap;
-  const uint32_t *cand_cnt, *cand_key, *list_shard, *list_len;
-  const float *cand_dist;
+  SelectCommon c;
+  uint32_t nq, P;
+  const float4 *blocks;  // centroid table
+  const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt, *overflow;
 };
 
@@ -421,24 +441,49 @@ struct CoarseSelectArgs {
 // order (the reference's stable sort, ivf_index.rs:205-220), then shard visiting order + histogram as in
 // coarse_merge_kernel
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ uint32_t s_pick[4][128];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  const uint32_t n = a.cand_cnt[q];
-  if (n > a.cap || n < a.P) {  // cannot happen with a finite bound unless the list overflowed
+  const SelectCommon &c = a.c;
+  const uint32_t n = c.cand_cnt[q];
+  if (n > c.cap || n < a.P) {  // cannot happen with a finite bound unless the list overflowed
     if (lane == 0) atomicAdd(a.overflow, 1u);
     return;
   }
+  const float thr2 = select_threshold(c, q, n, a.P, lane);
   WaveTopK sel;
   sel.init();
   const int K = (int)a.P;
+  const float *qrow = c.Q + (size_t)q * c.dim;
+  uint32_t *pick = s_pick[wave];
+  uint32_t npick = 0;
+  auto flush = [&](uint32_t off, uint32_t cnt) {
+    const bool live = (uint32_t)lane < cnt;
+    const uint32_t pos = live ? (pick[off + lane] & ((1u << kPosBits) - 1u)) : 0u;
+    float d = INFINITY;
+    if (live) d = exact_pair(qrow, a.blocks + ((size_t)(pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
+    sel.offer(d, live ? pos : kNoPos, K);
+  };
   for (uint32_t base = 0; base < n; base += kWave) {
     const uint32_t i = base + lane;
-    const bool live = i < n;
-    const float d = live ? a.cand_dist[(size_t)q * a.cap + i] : INFINITY;
-    const uint32_t key = live ? (a.cand_key[(size_t)q * a.cap + i] & ((1u << kPosBits) - 1u)) : kNoPos;
-    sel.offer(d, key, K);
+    const bool pass = i < n && c.cand_dist[(size_t)q * c.cap + i] <= thr2;
+    const uint64_t m = __ballot(pass);
+    const uint32_t cntp = (uint32_t)__popcll(m);
+    if (npick + cntp > 128) {
+      __builtin_amdgcn_wave_barrier();
+      while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
+      if (npick) { flush(0, npick); npick = 0; }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (pass) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c.cand_key[(size_t)q * c.cap + i];
+    npick += cntp;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
+  if (npick) flush(0, npick);
   const uint32_t found = a.P;
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
@@ -603,8 +648,11 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   }
   // d. select the P probes, shard order, histogram
   {
-    CoarseSelectArgs a{(uint32_t)nq, P, kCap, ws.cand_cnt.p, ws.cand_key.p, ix.list_shard.p, ix.list_len.p,
-                       ws.cand_dist.p, ws.probes.p, ws.gorder.p, ws.cnt.p, ws.cand_cnt.p + nq};
+    FilterArgs m{};
+    filter_margins(m, dim, ix.cent_xmax2);
+    SelectCommon c{Qd, dim, dq, kCap, ws.cand_cnt.p, ws.cand_key.p, ws.cand_dist.p, m.gamma2 * 0.5f, m.e_scale, m.xmax2};
+    CoarseSelectArgs a{c, (uint32_t)nq, P, (const float4 *)ix.centroids.blocks.p, ix.list_shard.p, ix.list_len.p,
+                       ws.probes.p, ws.gorder.p, ws.cnt.p, ws.cand_cnt.p + nq};
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
@@ -696,9 +744,11 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----
   {
-    SelectArgs a{(uint32_t)nq, P, (uint32_t)k, kCap, ws.cand_cnt.p, ws.cand_key.p, ws.probes.p, ws.gorder.p,
-                 ix.list_first_block.p, ws.cand_dist.p, ws.tau.p, ix.ext_ids.p, Dd, Id, Td, slots, counts,
-                 ws.fallback.p};
+    FilterArgs m{};
+    filter_margins(m, dim, ix.xmax2);
+    SelectCommon c{Qd, dim, dq, kCap, ws.cand_cnt.p, ws.cand_key.p, ws.cand_dist.p, m.gamma2 * 0.5f, m.e_scale, m.xmax2};
+    SelectArgs a{c, (uint32_t)nq, P, (uint32_t)k, (const float4 *)ix.lists.blocks.p, ws.probes.p, ws.gorder.p,
+                 ix.list_first_block.p, ws.tau.p, ix.ext_ids.p, Dd, Id, Td, slots, counts, ws.fallback.p};
     hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
