@@ -203,11 +203,12 @@ def test_generic_path_equals_fast_path(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("n,d,nlist,kind", [(20000, 64, 0, "gauss"), (6000, 128, 24, "gauss"), (4000, 96, 0, "gauss"),
-                                            (5000, 32, 12, "clustered"), (3000, 8, 40, "grid"), (9000, 100, 30, "sift")])
+                                            (5000, 32, 12, "clustered"), (3000, 8, 40, "grid"), (9000, 100, 30, "sift"),
+                                            (40000, 32, 1024, "gauss")])
 def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
-    """VI_FILTER=1 forces the f32-MFMA filter + exact re-check pipeline (filter_search.hip).  Its result must be
-    the oracle's, bit for bit, including ties, short lists (bound = inf -> exact pipeline) and overflowing
-    candidate lists (many duplicates -> exact pipeline)."""
+    """VI_FILTER=1 forces the f32-MFMA rank + exact re-evaluation pipeline (filter_search.hip).  Its result must
+    be the oracle's, bit for bit, including ties, lists shorter than k and masses of duplicates (whole-group
+    re-evaluation).  nlist >= 1024 with >= 256 queries also runs the coarse quantizer on the matrix cores."""
     rng = np.random.default_rng(n + d)
     if kind == "gauss":
         X = rng.standard_normal((n, d)).astype(np.float32)
@@ -231,13 +232,16 @@ def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
     check_parity(orc, gpu, Q, 10, 8)
 
 
-def test_mfma_filter_candidate_overflow_falls_back(tmp_path, monkeypatch):
+def test_mfma_filter_duplicates_reevaluate_whole_groups(tmp_path, monkeypatch):
     rng = np.random.default_rng(5)
     base = rng.standard_normal((3, 16)).astype(np.float32)
-    X = np.repeat(base, 18000, axis=0)                                 # 18000 exact copies of each vector (> 16384 slots)
+    X = np.repeat(base, 18000, axis=0)                                 # 18000 exact copies of each vector
     X = X[rng.permutation(len(X))]
     orc, gpu = oracle_and_gpu(tmp_path, X, nlist=4)
     Q = np.concatenate([base, rng.standard_normal((60, 16)).astype(np.float32)])
     monkeypatch.setenv("VI_FILTER", "1")
+    gpu.enable_timing(True)
     check_parity(orc, gpu, Q, 10, 4)
-    assert gpu.last_stats()["fallback_queries"] > 0
+    st = gpu.last_stats()
+    assert st["filter_accepted"] > 0          # records whose 4th value ties the threshold: whole groups re-evaluated
+    assert st["fallback_queries"] == 0

@@ -58,9 +58,10 @@ struct SearchWorkspace {
   DevBuf<float> V;
   // generic (large k / n_probe) path
   // MFMA filter path (filter_search.hip)
-  DevBuf<uint32_t> probes0, cand_cnt, cand_key, c_seg, c_item, c_pairs;
-  DevBuf<float> tau, cand_dist;
-  DevBuf<uint8_t> fallback;
+  DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list
+  DevBuf<uint32_t> pair_rel, qtot, qoff;    // record offsets: per (query, probe), per query, scan over queries
+  DevBuf<float> gval;                       // records: 4 smallest values per (query, probe, segment, lane half)
+  DevBuf<uint32_t> gpos;                    // ... and their positions
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

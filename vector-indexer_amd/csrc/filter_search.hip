@@ -1,29 +1,37 @@
-// filter_search.hip — list scan on the matrix cores: f32-MFMA filter + exact-order re-check.
+// filter_search.hip — list scan and coarse quantizer on the matrix cores: f32-MFMA ranking +
+// exact-order re-evaluation of the few vectors that can be results.
 //
 // The exact-order VALU scan (search_kernels.hip) spends 3 vector ops per (query, vector, dim) and is
 // bound by f32 VALU issue.  When many queries of a batch probe the same list, (queries x vectors x
-// dims) is GEMM shaped, so the bulk of the candidates can be REJECTED on the matrix cores and only
-// the few survivors need the reference's exact arithmetic:
+// dims) is GEMM shaped: the matrix cores can RANK the candidates, and only the handful that can
+// reach the top-k need the reference's exact arithmetic (src/utils.rs:28-30).
 //
-//   1. bound     tau_q = k-th smallest EXACT distance among the first 512 vectors of the query's
-//                nearest list (existing scan kernel, max_blocks = 8).  Any k exact candidates
-//                bound the final k-th distance from above, so every true result has d_ref <= tau_q.
-//   2. filter    per (list, tile of 32 queries): m(q,v) = ||v||^2 - 2 q.v with
-//                v_mfma_f32_32x32x2_f32 (A = 32 vectors straight from the lane-interleaved blocks,
-//                B = the tile's queries held in registers, accumulator initialised with ||v||^2).
-//                (q,v) survives iff m <= thr_q, where
-//                    thr_q = tau_q (1 + 2 gamma) + E_q - ||q||^2 (lower bound)
-//                    gamma = (D+2) u'            rounding of the reference's sequential sum
-//                    E_q   = (D+2) u' (||q||^2 + 2 max ||v||^2)   rounding of the fma chain + norms
-//                so d_ref(q,v) <= tau_q  ==>  m(q,v) <= thr_q  (no true result is ever rejected).
-//   3. re-check  survivors are compacted across the tile (one lane per (q,v) pair, 64 pairs per
-//                pass), their distance is recomputed in the reference's exact order and those with
-//                d_ref <= tau_q are appended to the query's candidate list.
-//   4. select    one wave per query: wave-resident top-k over its candidates with the reference's
-//                stable order (dist, shard-visit order, position) -> D, I, tie.
+//   1. rank      per work item (list segment of <= segb blocks, group of <= 128 queries):
+//                m(q,v) = ||v||^2 - 2 q.v with v_mfma_f32_32x32x2_f32 (A = 64 vectors staged in LDS,
+//                B = the group's queries in registers, accumulator initialised with ||v||^2).
+//                A lane owns one query and 32 of the 64 rows of every block.  Per block it keeps
+//                the two smallest values b1 <= b2 of its 32 (the row index rides in the 5 low
+//                mantissa bits, so min/med3 carry it for free); per segment it keeps the four
+//                smallest of all b1/b2 with their positions: T0 <= T1 <= T2 <= T3.  One 32-byte
+//                record per (query, probe, segment, lane half) is written when the item ends — no
+//                thresholds, no atomics, no candidate lists, nothing that can overflow.
+//   2. select    one wave per query reads its records (~4 values per 512 scanned vectors).
+//                With m_K the K-th smallest recorded value, every vector of the true top-K has
+//                    m <= thr = m_K + 2E + 3 gamma (m_K + ||q||^2 + E)            (*)
+//                    gamma = (D+2) u'                      rounding of the reference's sequential sum
+//                    E     = ((D+2) u' + 2^-18)(||q||^2 + 2 max||v||^2)   MFMA chain, norms, packed bits
+//                because the K recorded vectors below m_K already bound the K-th reference distance.
+//                What a record does not list is bounded by what it does:
+//                  - values dropped from T are >= T3, so T3 <= thr  => the whole group is re-evaluated;
+//                  - the unlisted rows of a block are >= its b2, so a listed b2 <= thr => that
+//                    lane-block (32 vectors) is re-evaluated;
+//                  - otherwise only the listed vectors with value <= thr are.
+//                Re-evaluation = the reference's exact sequential f32 distance; the top-K of those under
+//                the reference's stable order (distance, shard visiting order, position) is the answer,
+//                bit for bit (tests/test_search_gpu.py).
 //
-// Queries whose bound is infinite (nearest list shorter than k) or whose candidate list overflows
-// go through the exact VALU pipeline instead; results are bit-identical on both paths.
+// The coarse quantizer (ivf_index.rs:205-220) is the same computation with the centroid table as one
+// list probed by every query and K = n_probe.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -41,28 +49,25 @@ namespace vi {
 
 // provided by search_kernels.hip
 vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
-vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
-                               float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                               bool timing);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[3], hipStream_t st);
+                          uint64_t hstats[5], hipStream_t st, bool histogram_done);
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
-constexpr int kGroupQ = 128;            // queries per work item: 4 waves x one MFMA column tile of 32
-constexpr uint32_t kSampleBlocks = 8;   // blocks of the nearest list sampled for the bound
-constexpr uint32_t kCap = 16384;        // candidate slots per query
-constexpr uint32_t kSampleRanks = 2;    // nearest lists sampled for the bound (<= 4)
-constexpr uint32_t kPosBits = 26;       // candidate key = (probe rank << 26) | position in list
+constexpr int kGroupQ = 128;       // queries per work item: 4 waves x one MFMA column tile of 32
+constexpr uint32_t kPosBits = 26;  // candidate key = (probe rank << 26) | position in list
+constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
+constexpr uint32_t kB2Flag = 0x80000000u;  // record position flag: the value is a block's SECOND smallest
+constexpr float kBig = 3.0e38f;            // norm of pad slots inside the kernel (finite: low bits are reused)
 
 __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, const uint64_t *ext_ids,
                                   float *xnorm, uint32_t *xmax_bits) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
-  float out = INFINITY;  // pad slots never pass the filter
+  float out = INFINITY;  // pad slots never rank
   if (!ext_ids || ext_ids[s] != ~0ull) {
     double acc = 0.0;
     const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
@@ -76,33 +81,55 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
   xnorm[s] = out;
 }
 
-__global__ void take_first_ranks_kernel(const uint32_t *probes, uint32_t nq, uint32_t P, uint32_t R0,
-                                        uint32_t *probes0) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nq * R0) probes0[t] = probes[(size_t)(t / R0) * P + (t % R0)];
-}
-
-// tau_q = k-th smallest exact distance over the union of the query's R0 sampled runs (each sorted, K entries)
-__global__ void tau_kernel(const float *run_dist, const uint32_t *run_pos, uint32_t nq, uint32_t R0, uint32_t K,
-                           uint32_t k, float *tau) {
+// ------------------------------------------------------------------------------------------
+// record bookkeeping: where the records of (query, probe) start
+// ------------------------------------------------------------------------------------------
+// rel[q*P+r] = records of the query's probes before rank r ; qtot[q] = records of the query
+__global__ void pair_groups_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nq, uint32_t P,
+                                   uint32_t segb0, uint32_t *rel, uint32_t *qtot) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  uint32_t head[4] = {0, 0, 0, 0};
-  float last = INFINITY;
-  for (uint32_t i = 0; i < k; ++i) {
-    float best = INFINITY;
-    int br = -1;
-    for (uint32_t r = 0; r < R0; ++r) {
-      const size_t o = ((size_t)q * R0 + r) * K + head[r];
-      if (head[r] < K && run_pos[o] != kNoPos && (br < 0 || run_dist[o] < best)) { best = run_dist[o]; br = (int)r; }
+  uint32_t run = 0;
+  for (uint32_t r = 0; r < P; ++r) {
+    const uint32_t l = probes[(size_t)q * P + r];
+    rel[(size_t)q * P + r] = run;
+    if (l != kNoPos) {
+      uint32_t sb;
+      run += 2u * list_segments(list_len[l], segb0, &sb);
     }
-    if (br < 0) { last = INFINITY; break; }
-    head[br]++;
-    last = best;
   }
-  tau[q] = last;
+  qtot[q] = run;
 }
 
+// qoff = exclusive scan of qtot over the queries (one workgroup), qoff[nq] = total
+__global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
+  __shared__ uint32_t s[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (nq + 1023) / 1024;
+  const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
+  uint32_t sum = 0;
+  for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
+  s[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t a = t >= off ? s[t - off] : 0u;
+    __syncthreads();
+    s[t] += a;
+    __syncthreads();
+  }
+  uint32_t run = s[t] - sum;
+  for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
+  if (t == 1023) qoff[nq] = s[1023];
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// rank kernel
+// ------------------------------------------------------------------------------------------
 struct FilterArgs {
   const float4 *blocks;
   const float *xnorm;
@@ -110,18 +137,15 @@ struct FilterArgs {
   const float *Q;
   const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs;
   uint32_t nlists, P, segb0;
-  const float *tau;
-  float gamma2, e_scale, xmax2;
-  uint32_t cap;
-  uint32_t *cand_cnt;
-  float *cand_dist;
-  uint32_t *cand_key;
-  unsigned long long *dbg;  // [4]=pairs re-checked, [5]=pairs accepted
-  uint32_t xmode;           // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no compaction, 4 = no barriers
+  const uint32_t *qoff, *rel;  // record offsets (lists) ...
+  uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
+  float4 *gval;
+  uint4 *gpos;
+  uint32_t xmode;  // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no ranking epilogue
 };
 
-// Workgroup = 4 waves = up to 128 queries (4 column tiles of 32) probing ONE list (segment).  Every
-// 64-vector block of the list is staged once per workgroup into LDS as 64 rows of dq*4 floats (row stride
+// Workgroup = 4 waves = up to 128 queries (4 column tiles of 32) probing ONE list segment.  Every
+// 64-vector block of the segment is staged once per workgroup into LDS as 64 rows of dq*4 floats (row stride
 // 132 floats => conflict-free ds_read_b128 / ds_write_b128) together with the 64 squared norms, and is
 // consumed by all four waves; the next block's global loads are issued before the MFMAs of the current
 // one and written to LDS after them (issue-early / write-late), as in assign_mfma.hip.
@@ -143,8 +167,8 @@ __device__ __forceinline__ void stage_load(StageRegs<NG> &s, const float4 *src, 
     s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) s.v[i] = src[threadIdx.x + 256 * i];  // idx = quad*64 + vector: fully coalesced
   }
-  s.norm = INFINITY;
-  if (live && threadIdx.x < 64) s.norm = xn[threadIdx.x];
+  s.norm = kBig;
+  if (live && threadIdx.x < 64) s.norm = fminf(xn[threadIdx.x], kBig);
 }
 
 template <int NG>
@@ -157,8 +181,28 @@ __device__ __forceinline__ void stage_write(const StageRegs<NG> &s, float *tile)
   if (threadIdx.x < 64) tile[64 * kRowStride + threadIdx.x] = s.norm;
 }
 
+// value with the element index e (0..31) in its 5 low mantissa bits: |packed - m| < 2^-18 |m|
+__device__ __forceinline__ float pack_idx(float m, uint32_t e) {
+  return __uint_as_float((__float_as_uint(m) & ~31u) | e);
+}
+
+// sorted insert of (v, pos) into T0 <= T1 <= T2 <= T3
+#define VI_INS(Ti, Pi)        \
+  {                           \
+    const bool c_ = v < Ti;   \
+    const float tv_ = Ti;     \
+    const uint32_t tp_ = Pi;  \
+    Ti = c_ ? v : tv_;        \
+    Pi = c_ ? pos : tp_;      \
+    v = c_ ? tv_ : v;         \
+    pos = c_ ? tp_ : pos;     \
+  }
+
+#ifndef VI_FILTER_OCC
+#define VI_FILTER_OCC 3
+#endif
 template <int NG>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
-__global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
+__global__ void __launch_bounds__(256, VI_FILTER_OCC) filter_kernel(FilterArgs a) {
   __shared__ float s_tile[kTileFloats];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -181,42 +225,26 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
   const uint32_t nblk = (len + kWave - 1) / kWave;
   const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
 
-  // ---- this lane's query: wave w owns queries 32w .. 32w+31 of the group; both lane halves hold query j ----
-  const uint32_t jq_grp = 32u * wave + (uint32_t)j;
+  // ---- this lane's query: both lane halves hold query j of the wave's tile ----
+  // the tile a wave owns rotates with the item so that partially filled groups do not always idle the same SIMD
+  const uint32_t wtile = ((uint32_t)wave + item) & 3u;
+  const uint32_t jq_grp = 32u * wtile + (uint32_t)j;
   const bool qlive = jq_grp < nqi;
-  const bool wave_live = 32u * wave < nqi;  // wave-uniform
+  const bool wave_live = 32u * wtile < nqi;  // wave-uniform
   const uint32_t slot = qlive ? a.pairs[s0 + j0 + jq_grp] : 0u;
   const uint32_t qid = slot / a.P;
   const float *qrow = a.Q + (size_t)qid * a.dim;
   float4 qf[NG];
-  float qn = 0.0f;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const uint32_t e = 8 * g + 4 * h;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qlive && e < a.dim) v = *reinterpret_cast<const float4 *>(qrow + e);
-    qn += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     qf[g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
   }
-  qn += __shfl_xor(qn, 32);
-  const float tau = qlive ? a.tau[qid] : -INFINITY;
-  // thr on m = ||v||^2 - 2 q.v ; an infinite bound means "handled by the exact pipeline": reject all
-  float thr = -INFINITY;
-  if (qlive && tau < INFINITY) {
-    const float qn_hi = qn * (1.0f + a.gamma2), qn_lo = qn * (1.0f - a.gamma2);
-    thr = (tau * (1.0f + a.gamma2) + a.e_scale * (qn_hi + 2.0f * a.xmax2)) * 1.0001f - qn_lo;
-  }
 
-  // survivors are appended straight to their query's candidate list as (m, key): m = ||v||^2 - 2 q.v is the
-  // MFMA value; the select kernel decides which of them need the exact arithmetic
-  const uint32_t rkey = (slot - qid * a.P) << kPosBits;
-  auto emit = [&](float m, uint32_t pos) {
-    const uint32_t idx = atomicAdd(&a.cand_cnt[qid], 1u);
-    if (idx < a.cap) {
-      a.cand_dist[(size_t)qid * a.cap + idx] = m;
-      a.cand_key[(size_t)qid * a.cap + idx] = rkey | pos;
-    }
-  };
+  float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
+  uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos, P3 = kNoPos;
 
   StageRegs<NG> stage;
   stage_load<NG>(stage, a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, b0 < b1);
@@ -250,11 +278,33 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
       }
       if (!(a.xmode & 2u)) {
-        const uint32_t pbase = blk * kWave + 4u * (uint32_t)h;
+        // the two smallest of this lane's 32 values, element index in the low bits
+        float bm1 = INFINITY, bm2 = INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // reg r <-> vector row (r&3) + 8*(r>>2) + 4*h of its 32-row tile
-          if (acc0[r] <= thr) emit(acc0[r], pbase + (r & 3) + 8 * (r >> 2));
-          if (acc1[r] <= thr) emit(acc1[r], pbase + 32u + (r & 3) + 8 * (r >> 2));
+        for (int r = 0; r < 16; ++r) {
+          const float p = pack_idx(acc0[r], (uint32_t)r);
+          bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
+          bm1 = fminf(bm1, p);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = pack_idx(acc1[r], 16u + (uint32_t)r);
+          bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
+          bm1 = fminf(bm1, p);
+        }
+        // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
+        const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
+        {
+          const uint32_t e = __float_as_uint(bm1) & 31u, r = e & 15u;
+          float v = bm1;
+          uint32_t pos = pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2);
+          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) VI_INS(T3, P3)
+        }
+        {
+          const uint32_t e = __float_as_uint(bm2) & 31u, r = e & 15u;
+          float v = bm2;
+          uint32_t pos = (pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2)) | kB2Flag;
+          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) VI_INS(T3, P3)
         }
       }
     }
@@ -262,24 +312,32 @@ __global__ void __launch_bounds__(256, 2) filter_kernel(FilterArgs a) {
     if (more) stage_write<NG>(stage, s_tile);
     if (!(a.xmode & 4u)) __syncthreads();  // next tile visible
   }
+  if (qlive) {
+    const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
+    a.gval[gi] = make_float4(T0, T1, T2, T3);
+    a.gpos[gi] = make_uint4(P0, P1, P2, P3);
+  }
 }
 
-
 // ------------------------------------------------------------------------------------------
-// select: which survivors need the reference's exact arithmetic, and the final top-K
+// select
 // ------------------------------------------------------------------------------------------
-// A query's candidate list holds (m, key) with m = ||v||^2 - 2 q.v from the MFMA.  Let m_K be the K-th
-// smallest m.  The K candidates with the smallest m have d_ref <= (m_K + ||q||^2 + E)(1 + gamma), so the K-th
-// smallest d_ref is at most that, and every candidate of the true top-K satisfies
-//     m <= m_K + 2E + 3 gamma (m_K + ||q||^2 + E)                                   (*)
-// Only candidates passing (*) (K plus a handful) are re-evaluated in exact order; the top-K of those exact
-// distances under the reference's stable order is the answer.
 struct SelectCommon {
   const float *Q;
-  uint32_t dim, dq, cap;
-  const uint32_t *cand_cnt, *cand_key;
-  const float *cand_dist;
+  uint32_t dim, dq;
+  const float4 *blocks;
+  const float4 *gval;
+  const uint4 *gpos;
   float gamma, e_scale, xmax2;
+  unsigned long long *dbg;  // [6] exact re-evaluations, [7] whole-group re-evaluations
+};
+
+// the query's probes, one per lane r < P
+struct ProbeRegs {
+  uint32_t rel, ng;   // first record / number of records of the probe
+  uint32_t len, fb;   // list length and first block
+  uint32_t segb;      // blocks per segment
+  uint32_t g;         // candidate-order rank (shard visiting order)
 };
 
 // exact distance of one (query row, stored vector) pair, one lane per pair (src/utils.rs:28-30)
@@ -305,104 +363,182 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
   return acc;
 }
 
-// stage 1 of the select: threshold (*) on m for query q with n candidates (wave-uniform result)
-__device__ __forceinline__ float select_threshold(const SelectCommon &c, uint32_t q, uint32_t n, uint32_t K, int lane) {
-  WaveTopK s1;
-  s1.init();
-  for (uint32_t base = 0; base < n; base += kWave) {
-    const uint32_t i = base + lane;
-    const bool live = i < n;
-    s1.offer(live ? c.cand_dist[(size_t)q * c.cap + i] : INFINITY, live ? i : kNoPos, (int)K);
-  }
-  if (n < K) return INFINITY;  // fewer candidates than wanted: all of them are results
-  const float mk = readlane_f(s1.d, (int)K - 1);
-  float qn = 0.0f;
-  for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
+// One wave: top-K of query q under (exact distance, (g << 26) | position) from its G records at gbase.
+// Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
+__device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
+                                            const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick,
+                                            WaveTopK &sel) {
+  // ---- stage 1: threshold (*) from the K-th smallest recorded value ----
+  float thr = INFINITY;
+  {
+    const float *vals = reinterpret_cast<const float *>(c.gval + gbase);
+    const uint32_t n4 = 4u * G;
+    WaveTopK s1;
+    s1.init();
+    for (uint32_t base = 0; base < n4; base += kWave) {
+      const uint32_t i = base + lane;
+      const bool live = i < n4;
+      s1.offer(live ? vals[i] : INFINITY, live ? i : kNoPos, (int)K);
+    }
+    const float mk = n4 >= K ? readlane_f(s1.d, (int)K - 1) : INFINITY;
+    if (mk < 1.0e37f) {
+      float qn = 0.0f;
+      for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
-  const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
-  const float scale = fmaxf(mk + qn, 0.0f) + E;
-  return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+      for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+      const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+      const float scale = fmaxf(mk + qn, 0.0f) + E;
+      thr = mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+    }
+  }
+  // ---- stage 2: exact re-evaluation of what can be at or below thr ----
+  sel.init();
+  const float *qrow = c.Q + (size_t)q * c.dim;
+  uint32_t n_exact = 0, n_full = 0;
+  auto exact_offer = [&](bool live, uint32_t r, uint32_t pos) {  // one (probe rank, position) per lane
+    const uint32_t fb = (uint32_t)__shfl((int)pr.fb, (int)r);
+    const uint32_t g = (uint32_t)__shfl((int)pr.g, (int)r);
+    const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
+    live = live && pos < len;
+    float d = INFINITY;
+    if (live) d = exact_pair(qrow, c.blocks + ((size_t)(fb + pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
+    n_exact += (uint32_t)__popcll(__ballot(live));
+    sel.offer(d, live ? ((g << kPosBits) | pos) : kNoPos, (int)K);
+  };
+  uint32_t npick = 0;
+  auto drain = [&]() {
+    while (npick > 0) {
+      const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
+      npick -= cnt;
+      const bool live = (uint32_t)lane < cnt;
+      const uint32_t ck = live ? pick[npick + lane] : 0u;
+      exact_offer(live, ck >> kPosBits, ck & kPosMask);
+    }
+  };
+  for (uint32_t gb = 0; gb < G; gb += kWave) {
+    const uint32_t gidx = gb + lane;
+    const bool live = gidx < G;
+    uint32_t r = 0;
+    for (uint32_t rr = 0; rr < P; ++rr) {
+      const uint32_t rel = readlane_u(pr.rel, (int)rr), ng = readlane_u(pr.ng, (int)rr);
+      if (live && gidx >= rel && gidx < rel + ng) r = rr;
+    }
+    const uint32_t local = gidx - (uint32_t)__shfl((int)pr.rel, (int)r);
+    const uint32_t seg = local >> 1, hh = local & 1u;
+    const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
+    float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
+    if (live) { T = c.gval[gbase + gidx]; Pp = c.gpos[gbase + gidx]; }
+    const bool full = live && T.w <= thr;
+    const float tv[3] = {T.x, T.y, T.z};
+    const uint32_t tp[3] = {Pp.x, Pp.y, Pp.z};
+    bool pass[3], is2[3];
+    uint32_t blk[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pass[i] = live && !full && tv[i] <= thr && tp[i] != kNoPos && (tp[i] & kPosMask) < len;
+      is2[i] = (tp[i] & kB2Flag) != 0u;
+      blk[i] = (tp[i] & kPosMask) >> 6;
+    }
+    // listed vectors (a block's smallest, unless its lane-block is re-evaluated anyway)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      bool single = pass[i] && !is2[i];
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx)
+        if (jx != i && pass[jx] && is2[jx] && blk[jx] == blk[i]) single = false;
+      const uint64_t m = __ballot(single);
+      const uint32_t cntp = (uint32_t)__popcll(m);
+      if (npick + cntp > 128u) drain();
+      if (single) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (r << kPosBits) | (tp[i] & kPosMask);
+      npick += cntp;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // lane-blocks: a listed second-smallest at or below thr says nothing about the block's other rows
+    const int sub = lane & 31, e15 = sub & 15;
+    const uint32_t vrow = 32u * (uint32_t)(sub >> 4) + (uint32_t)(e15 & 3) + 8u * (uint32_t)(e15 >> 2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      uint64_t m = __ballot(pass[i] && is2[i]);
+      while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t rr = readlane_u(r, src), bb = readlane_u(blk[i], src), h2 = readlane_u(hh, src);
+        exact_offer(lane < 32, rr, bb * kWave + vrow + 4u * h2);
+      }
+    }
+    // whole groups: the fourth-smallest listed value is at or below thr
+    uint64_t m = __ballot(full);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint32_t rr = readlane_u(r, src), sg = readlane_u(seg, src), h2 = readlane_u(hh, src);
+      const uint32_t segb = readlane_u(pr.segb, (int)rr), ln = readlane_u(pr.len, (int)rr);
+      const uint32_t nblk = (ln + kWave - 1) / kWave;
+      const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
+      n_full++;
+      for (uint32_t b = bs; b < be; b += 2) {  // two blocks per pass: lanes 0-31 / 32-63
+        const uint32_t bb = b + (uint32_t)(lane >> 5);
+        exact_offer(bb < be, rr, bb * kWave + vrow + 4u * h2);
+      }
+    }
+  }
+  drain();
+  if (c.dbg && lane == 0) {
+    atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
+    atomicAdd(&c.dbg[7], (unsigned long long)n_full);
+  }
 }
 
 struct SelectArgs {
   SelectCommon c;
-  uint32_t nq, P, k;
-  const float4 *blocks;
-  const uint32_t *probes, *gorder, *first_block;
-  const float *tau;
+  uint32_t nq, P, k, segb0;
+  const uint32_t *qoff, *qtot, *rel;
+  const uint32_t *probes, *gorder, *first_block, *list_len;
   const uint64_t *ext_ids;
   float *D;
   int64_t *I;
   uint64_t *tie, *slots;
   uint32_t *counts;
-  uint8_t *fallback;
 };
 
-// one wave per query: top-k of its candidates in the reference's stable order
+// one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   __shared__ uint32_t s_pick[4][128];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  const SelectCommon &c = a.c;
-  const uint32_t n = c.cand_cnt[q];
-  const bool noinf = a.tau[q] < INFINITY;
-  const bool fb = !noinf || n > c.cap;
-  if (lane == 0) a.fallback[q] = !noinf ? 1 : (n > c.cap ? 2 : 0);
-  if (fb) return;
-  const uint32_t g_of_r = (uint32_t)lane < a.P ? a.gorder[(size_t)q * a.P + lane] : kNoPos;
-  const uint32_t list_of_r = (uint32_t)lane < a.P ? a.probes[(size_t)q * a.P + lane] : 0u;
-  const uint32_t fb_of_r = (uint32_t)lane < a.P && list_of_r != kNoPos ? a.first_block[list_of_r] : 0u;
-  const float thr2 = select_threshold(c, q, n, a.k, lane);
-  WaveTopK sel;
-  sel.init();
-  const int K = (int)a.k;
-  const float *qrow = c.Q + (size_t)q * c.dim;
-  uint32_t *pick = s_pick[wave];
-  uint32_t npick = 0;
-  auto flush = [&](uint32_t off, uint32_t cnt) {  // exact distances of pick[off..off+cnt), one lane each
-    const bool live = (uint32_t)lane < cnt;
-    const uint32_t ck = live ? pick[off + lane] : 0u;
-    const uint32_t r = ck >> kPosBits, pos = ck & ((1u << kPosBits) - 1u);
-    const uint32_t g = (uint32_t)__shfl((int)g_of_r, (int)r);
-    const uint32_t fbk = (uint32_t)__shfl((int)fb_of_r, (int)r);
-    float d = INFINITY;
-    if (live) d = exact_pair(qrow, a.blocks + ((size_t)(fbk + pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
-    sel.offer(d, live ? ((g << kPosBits) | pos) : kNoPos, K);
-  };
-  for (uint32_t base = 0; base < n; base += kWave) {
-    const uint32_t i = base + lane;
-    const bool pass = i < n && c.cand_dist[(size_t)q * c.cap + i] <= thr2;
-    const uint64_t m = __ballot(pass);
-    const uint32_t cntp = (uint32_t)__popcll(m);
-    if (npick + cntp > 128) {
-      __builtin_amdgcn_wave_barrier();
-      while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
-      if (npick) { flush(0, npick); npick = 0; }
-      __builtin_amdgcn_wave_barrier();
+  ProbeRegs pr{0u, 0u, 0u, 0u, 1u, kNoPos};
+  uint32_t mylist = kNoPos;
+  if ((uint32_t)lane < a.P) {
+    const size_t s = (size_t)q * a.P + lane;
+    mylist = a.probes[s];
+    pr.g = a.gorder[s];
+    pr.rel = a.rel[s];
+    if (mylist != kNoPos) {
+      pr.len = a.list_len[mylist];
+      pr.fb = a.first_block[mylist];
+      pr.ng = 2u * list_segments(pr.len, a.segb0, &pr.segb);
     }
-    if (pass) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c.cand_key[(size_t)q * c.cap + i];
-    npick += cntp;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
-  if (npick) flush(0, npick);
+  WaveTopK sel;
+  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], sel);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
-  const uint32_t g = sel.p >> kPosBits, pos = sel.p & ((1u << kPosBits) - 1u);
+  const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
   uint32_t r = 0;
   for (uint32_t rr = 0; rr < a.P; ++rr) {
-    const uint32_t gv = readlane_u(g_of_r, (int)rr);
+    const uint32_t gv = readlane_u(pr.g, (int)rr);
     if (gv == g) r = rr;
   }
-  const uint32_t found = n < a.k ? n : a.k;
+  const bool have = (uint32_t)lane < a.k && sel.p != kNoPos;
+  const uint32_t found = (uint32_t)__popcll(__ballot(have));
+  const uint32_t fbk = (uint32_t)__shfl((int)pr.fb, (int)r);
   if ((uint32_t)lane < a.k) {
     const size_t o = (size_t)q * a.k + lane;
-    if ((uint32_t)lane < found && sel.p != kNoPos) {
-      const uint32_t list = a.probes[(size_t)q * a.P + r];
-      const uint64_t gslot = (uint64_t)a.first_block[list] * kWave + pos;
+    if (have) {
+      const uint64_t gslot = (uint64_t)fbk * kWave + pos;
       a.D[o] = sel.d;
       a.I[o] = (int64_t)a.ext_ids[gslot];
       if (a.tie) a.tie[o] = ((uint64_t)g << 32) | pos;
@@ -417,101 +553,32 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   if (a.counts && lane == 0) a.counts[q] = found;
 }
 
-__global__ void iota_kernel(uint32_t *p, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
-}
-
-__global__ void coarse_tau_kernel(const float *run_dist, const uint32_t *run_pos, uint32_t nq, uint32_t P, float *tau) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
-  const size_t o = (size_t)q * P + (P - 1);
-  tau[q] = run_pos[o] == kNoPos ? INFINITY : run_dist[o];
-}
-
 struct CoarseSelectArgs {
-  SelectCommon c;
-  uint32_t nq, P;
-  const float4 *blocks;  // centroid table
+  SelectCommon c;  // blocks = centroid table
+  uint32_t nq, P, nlists, segb, recs;  // recs = records per query
   const uint32_t *list_shard, *list_len;
-  uint32_t *probes, *gorder, *cnt, *overflow;
+  uint32_t *probes, *gorder, *cnt;
 };
 
-// one wave per query: the P nearest centroids among the filter's survivors, in (distance, centroid index)
-// order (the reference's stable sort, ivf_index.rs:205-220), then shard visiting order + histogram as in
-// coarse_merge_kernel
+// one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
+// sort, ivf_index.rs:205-220), then shard visiting order + histogram as in coarse_merge_kernel
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
   __shared__ uint32_t s_pick[4][128];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  const SelectCommon &c = a.c;
-  const uint32_t n = c.cand_cnt[q];
-  if (n > c.cap || n < a.P) {  // cannot happen with a finite bound unless the list overflowed
-    if (lane == 0) atomicAdd(a.overflow, 1u);
-    return;
-  }
-  const float thr2 = select_threshold(c, q, n, a.P, lane);
+  ProbeRegs pr{0u, 0u, 0u, 0u, 1u, 0u};
+  if (lane == 0) { pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb; }
   WaveTopK sel;
-  sel.init();
-  const int K = (int)a.P;
-  const float *qrow = c.Q + (size_t)q * c.dim;
-  uint32_t *pick = s_pick[wave];
-  uint32_t npick = 0;
-  auto flush = [&](uint32_t off, uint32_t cnt) {
-    const bool live = (uint32_t)lane < cnt;
-    const uint32_t pos = live ? (pick[off + lane] & ((1u << kPosBits) - 1u)) : 0u;
-    float d = INFINITY;
-    if (live) d = exact_pair(qrow, a.blocks + ((size_t)(pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
-    sel.offer(d, live ? pos : kNoPos, K);
-  };
-  for (uint32_t base = 0; base < n; base += kWave) {
-    const uint32_t i = base + lane;
-    const bool pass = i < n && c.cand_dist[(size_t)q * c.cap + i] <= thr2;
-    const uint64_t m = __ballot(pass);
-    const uint32_t cntp = (uint32_t)__popcll(m);
-    if (npick + cntp > 128) {
-      __builtin_amdgcn_wave_barrier();
-      while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
-      if (npick) { flush(0, npick); npick = 0; }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (pass) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = c.cand_key[(size_t)q * c.cap + i];
-    npick += cntp;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  while (npick >= (uint32_t)kWave) { npick -= kWave; flush(npick, kWave); }
-  if (npick) flush(0, npick);
-  const uint32_t found = a.P;
+  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], sel);
+  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
-    if (a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
   }
-}
-
-__global__ void gather_queries_kernel(const float *Q, const uint32_t *ids, uint32_t n, uint32_t dim, float *out) {
-  const uint32_t r = blockIdx.x;
-  if (r >= n) return;
-  for (uint32_t e = threadIdx.x; e < dim; e += blockDim.x) out[(size_t)r * dim + e] = Q[(size_t)ids[r] * dim + e];
-}
-
-__global__ void scatter_results_kernel(const uint32_t *ids, uint32_t n, uint32_t k, const float *Ds, const int64_t *Is,
-                                       const uint64_t *Ts, const uint64_t *Ss, const uint32_t *Cs, float *D,
-                                       int64_t *I, uint64_t *T, uint64_t *S, uint32_t *Cn) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * k) return;
-  const uint32_t i = t / k, c = t % k;
-  const size_t o = (size_t)ids[i] * k + c;
-  D[o] = Ds[t];
-  I[o] = Is[t];
-  if (T) T[o] = Ts[t];
-  if (S) S[o] = Ss[t];
-  if (Cn && c == 0) Cn[ids[i]] = Cs[i];
 }
 
 template <int NG>
@@ -522,9 +589,40 @@ vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, hipStream_t st) 
   return VI_OK;
 }
 
+vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, hipStream_t st) {
+  switch (dq / 2) {  // dq is a multiple of 4
+    case 2: return launch_filter_t<2>(a, nitems, st);
+    case 4: return launch_filter_t<4>(a, nitems, st);
+    case 6: return launch_filter_t<6>(a, nitems, st);
+    case 8: return launch_filter_t<8>(a, nitems, st);
+    case 10: return launch_filter_t<10>(a, nitems, st);
+    case 12: return launch_filter_t<12>(a, nitems, st);
+    case 14: return launch_filter_t<14>(a, nitems, st);
+    case 16: return launch_filter_t<16>(a, nitems, st);
+    default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
+  }
+}
+
+SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2) {
+  const double u = 1.01 * std::ldexp(1.0, -24);
+  SelectCommon c{};
+  c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
+  c.gval = (const float4 *)ix.ws.gval.p; c.gpos = (const uint4 *)ix.ws.gpos.p;
+  c.gamma = (float)((ix.dim + 2.0) * u);
+  c.e_scale = (float)((ix.dim + 2.0) * u + 1.01 * std::ldexp(1.0, -18));
+  c.xmax2 = xmax2;
+  c.dbg = (unsigned long long *)ix.ws.stats.p;
+  return c;
+}
+
+uint32_t env_xmode() {
+  const char *xm = getenv("VI_FILTER_XMODE");
+  return xm ? (uint32_t)atoi(xm) : 0u;
+}
+
 }  // namespace
 
-// norms of the stored vectors (filter accumulator init) — called once after the blocks are built
+// norms of the stored vectors (MFMA accumulator init) — called once after the blocks are built
 vi_status compute_slot_norms(DeviceIndex *ix) {
   const uint64_t nslots = ix->lists.nblocks * kWave;
   VI_TRY(ix->xnorm.reserve(std::max<uint64_t>(1, nslots)));
@@ -542,7 +640,7 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   float f;
   std::memcpy(&f, &bits, 4);
   ix->xmax2 = f;
-  // the coarse table: pad slots (>= nlists) must never pass the filter
+  // the coarse table: pad slots (>= nlists) must never rank
   const uint64_t cslots = ix->centroids.nblocks * kWave;
   VI_TRY(ix->cent_xnorm.reserve(std::max<uint64_t>(1, cslots)));
   VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
@@ -569,97 +667,49 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   return VI_OK;
 }
 
-static vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, hipStream_t st) {
-  switch (dq / 2) {  // dq is a multiple of 4
-    case 2: return launch_filter_t<2>(a, nitems, st);
-    case 4: return launch_filter_t<4>(a, nitems, st);
-    case 6: return launch_filter_t<6>(a, nitems, st);
-    case 8: return launch_filter_t<8>(a, nitems, st);
-    case 10: return launch_filter_t<10>(a, nitems, st);
-    case 12: return launch_filter_t<12>(a, nitems, st);
-    case 14: return launch_filter_t<14>(a, nitems, st);
-    case 16: return launch_filter_t<16>(a, nitems, st);
-    default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
-  }
-}
-
-static void filter_margins(FilterArgs &a, uint32_t dim, float xmax2) {
-  const double u = 1.01 * std::ldexp(1.0, -24);
-  a.gamma2 = (float)(2.0 * (dim + 2.0) * u);
-  a.e_scale = (float)((dim + 2.0) * u);
-  a.xmax2 = xmax2;
-}
-
-// coarse quantizer on the matrix cores: the centroid table is one "list" probed by every query
-vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st,
-                              bool *done) {
+// coarse quantizer on the matrix cores: the centroid table is one "list" probed by every query.
+// Leaves probes / gorder and the per-list histogram (ws.cnt) behind, like stage_coarse.
+vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
   SearchWorkspace &ws = ix.ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
-  *done = false;
   VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
   VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
-  VI_TRY(ws.tau.reserve(nq));
-  // a. bound: exact top-P over the first 512 centroids of the table
-  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
-  const uint32_t sblk = std::min<uint32_t>(nblk_c, kSampleBlocks);
-  VI_TRY(ws.crun_dist.reserve(nq * P));
-  VI_TRY(ws.crun_pos.reserve(nq * P));
-  {
-    const int qg = pick_qg(dq, (double)nq, ix.order);
-    ScanArgs a{};
-    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
-    a.K = P; a.run_dist = ws.crun_dist.p; a.run_pos = ws.crun_pos.p;
-    a.nvec = (uint32_t)std::min<uint64_t>(nlists, (uint64_t)sblk * kWave); a.S = 1; a.bps = sblk;
-    VI_TRY(launch_scan(a, qg, ix.order, true, (uint32_t)((nq + qg - 1) / qg), st));
-    hipLaunchKernelGGL(coarse_tau_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.crun_dist.p,
-                       ws.crun_pos.p, (uint32_t)nq, P, ws.tau.p);
-    VI_HIP(hipGetLastError());
-  }
-  // b. one list, every query probes it: groups of 128 queries x segments of 4 blocks
+  // one list, every query probes it: groups of 128 queries x segments of segb blocks
   const uint32_t segb0 = 4;
   uint32_t segb;
   const uint32_t nseg = list_segments((uint32_t)nlists, segb0, &segb);
+  const uint32_t recs = 2u * nseg;
   const uint32_t ngroups = (uint32_t)((nq + kGroupQ - 1) / kGroupQ);
   const uint32_t h_seg[2] = {0u, (uint32_t)nq}, h_item[2] = {0u, ngroups * nseg};
   VI_TRY(ws.c_seg.reserve(2));
   VI_TRY(ws.c_item.reserve(2));
   VI_TRY(ws.c_pairs.reserve(nq));
+  VI_TRY(ws.gval.reserve(nq * recs * 4));
+  VI_TRY(ws.gpos.reserve(nq * recs * 4));
+  VI_TRY(ws.stats.reserve(8));
   VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
   VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.c_pairs.p, (uint32_t)nq);
-  // c. filter + exact re-check
-  VI_TRY(ws.cand_cnt.reserve(nq + 1));
-  VI_TRY(ws.cand_dist.reserve(nq * kCap));
-  VI_TRY(ws.cand_key.reserve(nq * kCap));
-  VI_TRY(ws.stats.reserve(8));
-  VI_HIP(hipMemsetAsync(ws.cand_cnt.p, 0, (nq + 1) * sizeof(uint32_t), st));
   {
     FilterArgs a{};
     a.blocks = (const float4 *)ix.centroids.blocks.p; a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
     a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
-    a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0; a.tau = ws.tau.p;
-    filter_margins(a, dim, ix.cent_xmax2);
-    a.dbg = (unsigned long long *)ws.stats.p;
-    a.cap = kCap; a.cand_cnt = ws.cand_cnt.p; a.cand_dist = ws.cand_dist.p; a.cand_key = ws.cand_key.p;
+    a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
+    a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
+    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, st));
   }
-  // d. select the P probes, shard order, histogram
   {
-    FilterArgs m{};
-    filter_margins(m, dim, ix.cent_xmax2);
-    SelectCommon c{Qd, dim, dq, kCap, ws.cand_cnt.p, ws.cand_key.p, ws.cand_dist.p, m.gamma2 * 0.5f, m.e_scale, m.xmax2};
-    CoarseSelectArgs a{c, (uint32_t)nq, P, (const float4 *)ix.centroids.blocks.p, ix.list_shard.p, ix.list_len.p,
-                       ws.probes.p, ws.gorder.p, ws.cnt.p, ws.cand_cnt.p + nq};
+    CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
+                       (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
+                       ws.cnt.p};
+    a.c.dbg = nullptr;
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
-  uint32_t overflow = 0;
-  VI_HIP(hipMemcpyAsync(&overflow, ws.cand_cnt.p + nq, 4, hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
-  *done = overflow == 0;  // otherwise the caller runs the exact VALU coarse step
   return VI_OK;
 }
 
@@ -668,7 +718,8 @@ bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint
   if (force && *force == '0') return false;
   if (ix.order != VI_ORDER_SCALAR || ix.dim > 128 || (ix.dim & 3) || ix.dim < 4) return false;
   if (k > kMaxSelect || P > kMaxSelect || P < 1) return false;
-  if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // candidate key holds position < 2^26
+  if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // record position < 2^26
+  if (!(ix.xmax2 < 1.0e30f) || !(ix.cent_xmax2 < 1.0e30f)) return false;  // norms must stay far below kBig
   if (force && *force == '1') return true;
   // worth it when query tiles fill up: on average >= 8 queries per probed list
   return (double)nq * P / (double)std::max<uint64_t>(1, ix.nlists) >= 8.0;
@@ -679,115 +730,63 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                                  bool timing) {
   SearchWorkspace &ws = ix.ws;
   vi_search_stats &stt = ix.stats;
-  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint32_t dq = ix.dq;
   const uint64_t nlists = ix.nlists;
+  (void)K;
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+  // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram ----
   {
-    bool done = false;
     const char *cf = getenv("VI_COARSE_FILTER");
-    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) VI_TRY(stage_coarse_filter(ix, Qd, nq, P, st, &done));
-    if (!done) VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) VI_TRY(stage_coarse_filter(ix, Qd, nq, P, st));
+    else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
-
-  // ---- 1. bound: exact top-k over the first 512 vectors of each of the query's nearest lists ----
-  const uint32_t R0 = std::min<uint32_t>(kSampleRanks, P);
-  VI_TRY(ws.probes0.reserve(nq * R0));
-  VI_TRY(ws.tau.reserve(nq));
-  VI_TRY(ws.run_dist.reserve(nq * R0 * K));
-  VI_TRY(ws.run_pos.reserve(nq * R0 * K));
-  VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * R0 * K * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(take_first_ranks_kernel, dim3((uint32_t)((nq * R0 + 255) / 256)), dim3(256), 0, st, ws.probes.p,
-                     (uint32_t)nq, P, R0, ws.probes0.p);
-  VI_HIP(hipGetLastError());
-  uint64_t hstats[3];
-  {
-    const int qg = pick_qg(dq, (double)nq * R0 / (double)std::max<uint64_t>(1, nlists), ix.order);
-    const uint32_t segb0 = 1u << 20;  // never segment here: only the first blocks are read
-    VI_TRY(launch_grouping(ix, ws.probes0.p, nq, R0, qg, segb0, hstats, st));
-    ScanArgs a{};
-    a.blocks = (const float4 *)ix.lists.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd; a.nq = (uint32_t)nq;
-    a.K = K; a.run_dist = ws.run_dist.p; a.run_pos = ws.run_pos.p;
-    a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
-    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = R0;
-    a.segb0 = segb0; a.segrun_start = ws.segrun_start.p; a.max_blocks = kSampleBlocks;
-    VI_TRY(launch_scan(a, qg, ix.order, false, (uint32_t)hstats[1], st));
-    hipLaunchKernelGGL(tau_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.run_dist.p, ws.run_pos.p,
-                       (uint32_t)nq, R0, K, (uint32_t)std::min<uint64_t>(k, K), ws.tau.p);
-    VI_HIP(hipGetLastError());
-  }
-  // ---- 2. group all (query, probe) pairs by list in tiles of 32 queries ----
+  // ---- 2. group all (query, probe) pairs by list; record offsets per pair ----
   const char *sb = getenv("VI_FILTER_SEGB");
   const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 16u;  // <= 1024 vectors per work item
-  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st));
+  VI_TRY(ws.pair_rel.reserve(nq * P));
+  VI_TRY(ws.qtot.reserve(nq));
+  VI_TRY(ws.qoff.reserve(nq + 1));
+  hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
+                     ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p);
+  hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
+  VI_HIP(hipGetLastError());
+  uint64_t hstats[5];
+  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st, true));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
+  stt.filter_tile_blocks = hstats[3];
+  const uint64_t nrec = hstats[4];
+  if (nrec >= (1ull << 31)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
+  VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
+  VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec) * 4));
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
-  // ---- 3. MFMA filter + exact re-check -> per-query candidate lists ----
-  VI_TRY(ws.cand_cnt.reserve(nq));
-  VI_TRY(ws.cand_dist.reserve(nq * kCap));
-  VI_TRY(ws.cand_key.reserve(nq * kCap));
-  VI_TRY(ws.fallback.reserve(nq));
-  VI_HIP(hipMemsetAsync(ws.cand_cnt.p, 0, nq * sizeof(uint32_t), st));
+  // ---- 3. rank on the matrix cores ----
   {
     FilterArgs a{};
-    a.blocks = (const float4 *)ix.lists.blocks.p; a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
+    a.blocks = (const float4 *)ix.lists.blocks.p; a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
-    a.tau = ws.tau.p;
-    filter_margins(a, dim, ix.xmax2);
-    a.dbg = (unsigned long long *)ws.stats.p;
-    { const char *xm = getenv("VI_FILTER_XMODE"); a.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
-    a.cap = kCap; a.cand_cnt = ws.cand_cnt.p; a.cand_dist = ws.cand_dist.p; a.cand_key = ws.cand_key.p;
+    a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
+    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p;
+    a.xmode = env_xmode();
     VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----
   {
-    FilterArgs m{};
-    filter_margins(m, dim, ix.xmax2);
-    SelectCommon c{Qd, dim, dq, kCap, ws.cand_cnt.p, ws.cand_key.p, ws.cand_dist.p, m.gamma2 * 0.5f, m.e_scale, m.xmax2};
-    SelectArgs a{c, (uint32_t)nq, P, (uint32_t)k, (const float4 *)ix.lists.blocks.p, ws.probes.p, ws.gorder.p,
-                 ix.list_first_block.p, ws.tau.p, ix.ext_ids.p, Dd, Id, Td, slots, counts, ws.fallback.p};
+    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2), (uint32_t)nq, P, (uint32_t)k, segb0,
+                 ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
+                 ix.ext_ids.p, Dd, Id, Td, slots, counts};
     hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
-  // ---- 5. queries without a finite bound / with an overflowing candidate list: exact pipeline ----
-  std::vector<uint8_t> hfb(nq);
-  VI_HIP(hipMemcpyAsync(hfb.data(), ws.fallback.p, nq, hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
-  std::vector<uint32_t> ids;
-  uint64_t n_inf = 0;
-  for (uint64_t q = 0; q < nq; ++q)
-    if (hfb[q]) { ids.push_back((uint32_t)q); n_inf += hfb[q] == 1; }
-  if (getenv("VI_FILTER_VERBOSE"))
-    fprintf(stderr, "[vi] filter fallback: %zu queries (%llu without a finite bound, %llu candidate overflow)\n",
-            ids.size(), (unsigned long long)n_inf, (unsigned long long)(ids.size() - n_inf));
-  stt.fallback_queries = ids.size();
-  {
+  if (timing) {
     uint64_t dbg[8];
-    VI_HIP(hipMemcpy(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost));
-    stt.filter_tile_blocks = dbg[3]; stt.filter_rechecked = dbg[4]; stt.filter_accepted = dbg[5];
-  }
-  if (!ids.empty()) {
-    const uint64_t m = ids.size();
-    DevBuf<uint32_t> d_ids, cs;
-    DevBuf<float> qs, ds;
-    DevBuf<int64_t> is;
-    DevBuf<uint64_t> ts, ss;
-    VI_TRY(d_ids.reserve(m)); VI_TRY(qs.reserve(m * dim)); VI_TRY(ds.reserve(m * k)); VI_TRY(is.reserve(m * k));
-    VI_TRY(ts.reserve(m * k)); VI_TRY(ss.reserve(m * k)); VI_TRY(cs.reserve(m));
-    VI_HIP(hipMemcpyAsync(d_ids.p, ids.data(), m * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(gather_queries_kernel, dim3((uint32_t)m), dim3(64), 0, st, Qd, d_ids.p, (uint32_t)m, dim, qs.p);
-    VI_HIP(hipGetLastError());
-    const uint64_t keep_scanned = stt.scanned_vectors, keep_items = stt.scan_items;
-    VI_TRY(search_valu_pipeline(ix, qs.p, m, k, P, K, ds.p, is.p, ts.p, ss.p, cs.p, st, false));
-    stt.scanned_vectors = keep_scanned; stt.scan_items = keep_items;
-    hipLaunchKernelGGL(scatter_results_kernel, dim3((uint32_t)((m * k + 255) / 256)), dim3(256), 0, st, d_ids.p,
-                       (uint32_t)m, (uint32_t)k, ds.p, is.p, ts.p, ss.p, cs.p, Dd, Id, Td, slots, counts);
-    VI_HIP(hipGetLastError());
+    VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
+    stt.filter_rechecked = dbg[6]; stt.filter_accepted = dbg[7];
   }
   return VI_OK;
 }

@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   uint32_t seg = 0, item = 0, run = 0;
-  unsigned long long vec = 0, tb = 0;
+  unsigned long long vec = 0, tb = 0, rec = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint32_t c = list_count(cnt, l);
     uint32_t segb;
@@ -395,8 +395,10 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * list_len[l];
     tb += (unsigned long long)((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
+    rec += 2ull * c * ns;
   }
-  atomicAdd((unsigned long long *)&stats[3], tb);
+  atomicAdd((unsigned long long *)&stats[3], tb);   // (query group, block) tiles
+  atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: records = 2 per (pair, segment)
   s_seg[t] = seg; s_item[t] = item; s_run[t] = run; s_vec[t] = vec;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -1135,7 +1137,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 // Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[3], hipStream_t st) {
+                          uint64_t hstats[5], hipStream_t st, bool histogram_done) {
   SearchWorkspace &ws = ix.ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1145,17 +1147,19 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(total));
   VI_TRY(ws.stats.reserve(8));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
-  hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total, P,
-                     ws.cnt.p);
+  if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
+    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total, P,
+                       ws.cnt.p);
+  }
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
                      ws.cnt.p + nlists * kSubBins, ws.stats.p);
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
                      ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
   VI_HIP(hipGetLastError());
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));
   return VI_OK;
 }

@@ -9,7 +9,8 @@ VI_ASSIGN_REFERENCE, VI_ASSIGN_EXACT = 0, 1
 
 _STATUS_NAME = {1: "InvalidInput", 2: "NotFound", 3: "InvalidData", 4: "Other", 5: "Io", 6: "Panic", 7: "Device"}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libvi_amd.so")
+LIB_PATH = os.environ.get("VI_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                      "libvi_amd.so")
 
 u64, u32, i32, i64, f32 = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_float
 vp = C.c_void_p
