@@ -1,34 +1,44 @@
 #!/usr/bin/env python3
-import os, sys, tempfile
-import numpy as np, torch
+"""Diagnostic: distribution of exact re-evaluations per query on the bench workload (MFMA path)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "vector-indexer_amd")]
-import oracle_lib as O
-import vector_indexer_py as vip
+os.environ["VI_FILTER"] = "1"
+import bench  # noqa: E402
+import vector_indexer_py as vip  # noqa: E402
+
 dev = torch.device("cuda", 0)
-n, d = 20000, 64
-rng = np.random.default_rng(n + d)
-X = rng.standard_normal((n, d)).astype(np.float32)
-tmp = tempfile.mkdtemp()
-orc = O.OracleIndex.build(X, tmp + "/index", tmp + "/shards")
-gpu = vip.load(tmp + "/index", tmp + "/shards", d)
-Q = np.concatenate([X[:100], (X[100:400] + 0.01 * rng.standard_normal((300, d))).astype(np.float32),
-                    rng.standard_normal((100, d)).astype(np.float32) * float(np.abs(X).mean() + 1)])
-xq = torch.from_numpy(Q).to(dev)
-nq, k, P = Q.shape[0], 10, 8
-def run(flt):
-    os.environ["VI_FILTER"] = flt
-    D = torch.empty((nq, k), dtype=torch.float32, device=dev); I = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    T = torch.empty((nq, k), dtype=torch.int64, device=dev)
+n, d, nlist, nq, k = 1_000_000, 128, 4096, 10000, 10
+xb, xq = bench.make_dataset(n, d, nq, 42, dev)
+work = "/tmp/vi_scan_bench"
+if not os.path.exists(work + "/index/index.bin"):
+    vip.build(xb.cpu().numpy(), work, nlist=nlist, now_secs=1_700_000_000)
+index = vip.load(work + "/index", work + "/shards", d)
+index.enable_timing(True)
+
+
+def evals(q0, q1, n_probe=16):
+    m = q1 - q0
+    D = torch.empty((m, k), dtype=torch.float32, device=dev)
+    I = torch.empty((m, k), dtype=torch.int64, device=dev)
+    sub = xq[q0:q1].contiguous()
+    index.search_device(sub.data_ptr(), m, k, n_probe, D.data_ptr(), I.data_ptr(), 0)
     torch.cuda.synchronize()
-    gpu.search_device(xq.data_ptr(), nq, k, P, D.data_ptr(), I.data_ptr(), T.data_ptr())
-    return D.cpu().numpy(), I.cpu().numpy(), T.cpu().numpy().view(np.uint64)
-D0, I0, T0 = run("0")
-D1, I1, T1 = run("1")
-bad = np.nonzero((I0 != I1).any(1))[0]
-print("bad", bad, gpu.last_stats())
-for q in bad[:4]:
-    print("q", q)
-    print(" valu I", I0[q].tolist()); print(" filt I", I1[q].tolist())
-    print(" valu tie", [(int(t >> 32), int(t & 0xffffffff)) for t in T0[q]])
-    print(" filt tie", [(int(t >> 32), int(t & 0xffffffff)) for t in T1[q]])
+    st = index.last_stats()
+    return st["filter_rechecked"], st["filter_accepted"], st["scanned_vectors"]
+
+
+per = []
+for c in range(0, nq, 100):
+    e, a, s = evals(c, c + 100)
+    per.append((e, a, s, c))
+per.sort(reverse=True)
+print("chunks (evals, consults, scanned, q0): top", per[:5], "median", per[len(per) // 2])
+e, a, s, c = per[0]
+single = sorted(((evals(q, q + 1) + (q,)) for q in range(c, c + 100)), reverse=True)
+print("heaviest chunk per query: top", single[:8], "median", single[50])

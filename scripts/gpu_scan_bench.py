@@ -48,6 +48,4 @@ def run(label, n_probe, reps=6, **env):
 for p in (16,):
     run("filter default", p)
     run("filter segb 8", p, VI_FILTER_SEGB=8)
-    run("filter segb 32", p, VI_FILTER_SEGB=32)
     run("filter no-rank-epilogue (xmode 2)", p, VI_FILTER_XMODE=2)
-    run("valu coarse", p, VI_COARSE_FILTER=0)

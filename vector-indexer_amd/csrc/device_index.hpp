@@ -59,9 +59,11 @@ struct SearchWorkspace {
   // generic (large k / n_probe) path
   // MFMA filter path (filter_search.hip)
   DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list
-  DevBuf<uint32_t> pair_rel, qtot, qoff;    // record offsets: per (query, probe), per query, scan over queries
-  DevBuf<float> gval;                       // records: 4 smallest values per (query, probe, segment, lane half)
+  DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
+  DevBuf<uint32_t> pair_relb, qtotb, qoffb; // block-record offsets
+  DevBuf<float> gval;                       // group records: 4 smallest values per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and their positions
+  DevBuf<float> brec;                       // block records: 4 smallest values per (query, probe, block, lane half)
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

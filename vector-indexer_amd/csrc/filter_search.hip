@@ -9,21 +9,25 @@
 //   1. rank      per work item (list segment of <= segb blocks, group of <= 128 queries):
 //                m(q,v) = ||v||^2 - 2 q.v with v_mfma_f32_32x32x2_f32 (A = 64 vectors staged in LDS,
 //                B = the group's queries in registers, accumulator initialised with ||v||^2).
-//                A lane owns one query and 32 of the 64 rows of every block.  Per block it keeps
-//                the two smallest values b1 <= b2 of its 32 (the row index rides in the 5 low
-//                mantissa bits, so min/med3 carry it for free); per segment it keeps the four
-//                smallest of all b1/b2 with their positions: T0 <= T1 <= T2 <= T3.  One 32-byte
-//                record per (query, probe, segment, lane half) is written when the item ends — no
-//                thresholds, no atomics, no candidate lists, nothing that can overflow.
-//   2. select    one wave per query reads its records (~4 values per 512 scanned vectors).
+//                A lane owns one query and 32 of the 64 rows of every block (a "lane-block").  Per
+//                block it keeps the four smallest values b1 <= .. <= b4 of its 32 (the row index
+//                rides in the 5 low mantissa bits, so min/med3 carry it for free) and stores them
+//                as a 16-byte BLOCK RECORD; per segment it keeps the four smallest of all b1/b2
+//                with their positions, T0 <= T1 <= T2 <= T3, stored as a 32-byte GROUP RECORD when
+//                the item ends — no thresholds, no atomics, no candidate lists, nothing that can
+//                overflow.
+//   2. select    one wave per query reads its group records (~4 values per 512 scanned vectors).
 //                With m_K the K-th smallest recorded value, every vector of the true top-K has
 //                    m <= thr = m_K + 2E + 3 gamma (m_K + ||q||^2 + E)            (*)
 //                    gamma = (D+2) u'                      rounding of the reference's sequential sum
 //                    E     = ((D+2) u' + 2^-18)(||q||^2 + 2 max||v||^2)   MFMA chain, norms, packed bits
 //                because the K recorded vectors below m_K already bound the K-th reference distance.
 //                What a record does not list is bounded by what it does:
-//                  - values dropped from T are >= T3, so T3 <= thr  => the whole group is re-evaluated;
-//                  - the unlisted rows of a block are >= its b2, so a listed b2 <= thr => that
+//                  - values dropped from T are >= T3, so T3 <= thr => every block record of the group
+//                    is consulted;
+//                  - the rows of a block not listed in T are >= its b2, so a listed b2 <= thr => that
+//                    block record is consulted;
+//                  - the rows missing from a block record are >= its b4, so b4 <= thr => the whole
 //                    lane-block (32 vectors) is re-evaluated;
 //                  - otherwise only the listed vectors with value <= thr are.
 //                Re-evaluation = the reference's exact sequential f32 distance; the top-K of those under
@@ -50,7 +54,7 @@ namespace vi {
 // provided by search_kernels.hip
 vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[5], hipStream_t st, bool histogram_done);
+                          uint64_t hstats[6], hipStream_t st, bool histogram_done);
 
 namespace {
 
@@ -67,7 +71,7 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
                                   float *xnorm, uint32_t *xmax_bits) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
-  float out = INFINITY;  // pad slots never rank
+  float out = kBig;  // pad slots never rank (finite: the kernel reuses the low mantissa bits)
   if (!ext_ids || ext_ids[s] != ~0ull) {
     double acc = 0.0;
     const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
@@ -76,7 +80,8 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
       acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
     out = (float)acc;
-    if (out < INFINITY) atomicMax(xmax_bits, __float_as_uint(out));
+    if (out < kBig) atomicMax(xmax_bits, __float_as_uint(out));
+    out = fminf(out, kBig);
   }
   xnorm[s] = out;
 }
@@ -84,42 +89,49 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
 // ------------------------------------------------------------------------------------------
 // record bookkeeping: where the records of (query, probe) start
 // ------------------------------------------------------------------------------------------
-// rel[q*P+r] = records of the query's probes before rank r ; qtot[q] = records of the query
+// rel[q*P+r] = group records of the query's probes before rank r ; qtot[q] = group records of the query ;
+// relb / qtotb = the same for block records (2 per 64-vector block of a probed list)
 __global__ void pair_groups_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nq, uint32_t P,
-                                   uint32_t segb0, uint32_t *rel, uint32_t *qtot) {
+                                   uint32_t segb0, uint32_t *rel, uint32_t *qtot, uint32_t *relb, uint32_t *qtotb) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  uint32_t run = 0;
+  uint32_t run = 0, runb = 0;
   for (uint32_t r = 0; r < P; ++r) {
     const uint32_t l = probes[(size_t)q * P + r];
     rel[(size_t)q * P + r] = run;
+    relb[(size_t)q * P + r] = runb;
     if (l != kNoPos) {
       uint32_t sb;
       run += 2u * list_segments(list_len[l], segb0, &sb);
+      runb += 2u * ((list_len[l] + 63u) / 64u);
     }
   }
   qtot[q] = run;
+  qtotb[q] = runb;
 }
 
-// qoff = exclusive scan of qtot over the queries (one workgroup), qoff[nq] = total
-__global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
-  __shared__ uint32_t s[1024];
+// qoff / qoffb = exclusive scans of qtot / qtotb over the queries (one workgroup), [nq] = totals
+__global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, const uint32_t *qtotb, uint32_t nq,
+                                                             uint32_t *qoff, uint32_t *qoffb) {
+  __shared__ uint32_t s[1024], sb[1024];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (nq + 1023) / 1024;
   const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
-  uint32_t sum = 0;
-  for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
+  uint32_t sum = 0, sumb = 0;
+  for (uint32_t i = beg; i < end; ++i) { sum += qtot[i]; sumb += qtotb[i]; }
   s[t] = sum;
+  sb[t] = sumb;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t a = t >= off ? s[t - off] : 0u;
+    const uint32_t a = t >= off ? s[t - off] : 0u, b = t >= off ? sb[t - off] : 0u;
     __syncthreads();
     s[t] += a;
+    sb[t] += b;
     __syncthreads();
   }
-  uint32_t run = s[t] - sum;
-  for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
-  if (t == 1023) qoff[nq] = s[1023];
+  uint32_t run = s[t] - sum, runb = sb[t] - sumb;
+  for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; qoffb[i] = runb; runb += qtotb[i]; }
+  if (t == 1023) { qoff[nq] = s[1023]; qoffb[nq] = sb[1023]; }
 }
 
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
@@ -137,48 +149,32 @@ struct FilterArgs {
   const float *Q;
   const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs;
   uint32_t nlists, P, segb0;
-  const uint32_t *qoff, *rel;  // record offsets (lists) ...
-  uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
+  const uint32_t *qoff, *rel;    // group-record offsets (lists) ...
+  const uint32_t *qoffb, *relb;  // ... block-record offsets ...
+  uint32_t rec_stride, brec_stride;  // ... or fixed numbers of records per slot when qoff is null (coarse table)
   float4 *gval;
   uint4 *gpos;
+  float4 *brec;
   uint32_t xmode;  // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no ranking epilogue
 };
 
 // Workgroup = 4 waves = up to 128 queries (4 column tiles of 32) probing ONE list segment.  Every
-// 64-vector block of the segment is staged once per workgroup into LDS as 64 rows of dq*4 floats (row stride
-// 132 floats => conflict-free ds_read_b128 / ds_write_b128) together with the 64 squared norms, and is
-// consumed by all four waves; the next block's global loads are issued before the MFMAs of the current
-// one and written to LDS after them (issue-early / write-late), as in assign_mfma.hip.
-constexpr int kRowStride = 132;
-constexpr int kTileFloats = 64 * kRowStride + 64;
-
-// block staging: 64 vectors x 2*NG quads over 256 threads => NG/2 float4 each (+ one norm for threads < 64)
-template <int NG>
-struct StageRegs {
-  static constexpr int kPerThread = (64 * 2 * NG) / 256;  // NG even => integral
-  float4 v[kPerThread];
-  float norm;
-};
+// 64-vector block of the segment is copied once per workgroup into LDS by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no ds_write) and consumed by all four waves.  The LDS image is the block verbatim —
+// [quad][vector] float4, so a lane's A fragment (quad 2g+h of vector j) is a conflict-free ds_read_b128 —
+// followed by the block's 64 squared norms.  With NBUF = 2 the next block lands in the other buffer while
+// this one is multiplied (one barrier per block); with NBUF = 1 the load is exposed and hidden by the other
+// workgroups of the CU (3 per CU instead of 2).
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 template <int NG>
-__device__ __forceinline__ void stage_load(StageRegs<NG> &s, const float4 *src, const float *xn, bool live) {
+__device__ __forceinline__ void tile_dma(float *tile, const float4 *src, const float *xn, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < StageRegs<NG>::kPerThread; ++i) {
-    s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) s.v[i] = src[threadIdx.x + 256 * i];  // idx = quad*64 + vector: fully coalesced
+  for (int i = 0; i < NG / 2; ++i) {  // 2*NG quads of 1 KiB, round-robin over the 4 waves
+    const int qd = wave + 4 * i;
+    __builtin_amdgcn_global_load_lds(src + qd * kWave + lane, (lds_ptr_t)(tile + qd * 256), 16, 0, 0);
   }
-  s.norm = kBig;
-  if (live && threadIdx.x < 64) s.norm = fminf(xn[threadIdx.x], kBig);
-}
-
-template <int NG>
-__device__ __forceinline__ void stage_write(const StageRegs<NG> &s, float *tile) {
-#pragma unroll
-  for (int i = 0; i < StageRegs<NG>::kPerThread; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    *reinterpret_cast<float4 *>(tile + (idx & 63) * kRowStride + (idx >> 6) * 4) = s.v[i];
-  }
-  if (threadIdx.x < 64) tile[64 * kRowStride + threadIdx.x] = s.norm;
+  if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
 }
 
 // value with the element index e (0..31) in its 5 low mantissa bits: |packed - m| < 2^-18 |m|
@@ -198,12 +194,10 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
     pos = c_ ? tp_ : pos;     \
   }
 
-#ifndef VI_FILTER_OCC
-#define VI_FILTER_OCC 3
-#endif
-template <int NG>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
-__global__ void __launch_bounds__(256, VI_FILTER_OCC) filter_kernel(FilterArgs a) {
-  __shared__ float s_tile[kTileFloats];
+template <int NG, int NBUF>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
+__global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterArgs a) {
+  constexpr int kTileFloats = 2 * NG * 256 + 64;
+  __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const uint32_t item = blockIdx.x;  // grid == number of items
@@ -245,29 +239,34 @@ __global__ void __launch_bounds__(256, VI_FILTER_OCC) filter_kernel(FilterArgs a
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
   uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos, P3 = kNoPos;
+  uint32_t bi = 0;  // this lane's first block record (record counts are checked < 2^32 on the host)
+  if (qlive) bi = (a.qoffb ? a.qoffb[qid] + a.relb[slot] : slot * a.brec_stride) + (uint32_t)h;
 
-  StageRegs<NG> stage;
-  stage_load<NG>(stage, a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, b0 < b1);
-  stage_write<NG>(stage, s_tile);
-  __syncthreads();
+  tile_dma<NG>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
+  __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
     const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
-    // next block: in flight during this block's MFMAs
-    stage_load<NG>(stage, a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave, a.xnorm + (size_t)(fb + blk + 1) * kWave, more);
+    const float *s_tile = s_tiles[NBUF == 2 ? ((blk - b0) & 1u) : 0];
+    // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
+    // barrier that ended the previous iteration)
+    if (NBUF == 2 && more)
+      tile_dma<NG>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+                   a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
       f32x16 acc0, acc1;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) live in regs 4*q4 .. 4*q4+3
-        const float4 n0 = *reinterpret_cast<const float4 *>(s_tile + 64 * kRowStride + 8 * q4 + 4 * h);
-        const float4 n1 = *reinterpret_cast<const float4 *>(s_tile + 64 * kRowStride + 32 + 8 * q4 + 4 * h);
+        const float4 n0 = *reinterpret_cast<const float4 *>(s_tile + 2 * NG * 256 + 8 * q4 + 4 * h);
+        const float4 n1 = *reinterpret_cast<const float4 *>(s_tile + 2 * NG * 256 + 32 + 8 * q4 + 4 * h);
         acc0[4 * q4 + 0] = n0.x; acc0[4 * q4 + 1] = n0.y; acc0[4 * q4 + 2] = n0.z; acc0[4 * q4 + 3] = n0.w;
         acc1[4 * q4 + 0] = n1.x; acc1[4 * q4 + 1] = n1.y; acc1[4 * q4 + 2] = n1.z; acc1[4 * q4 + 3] = n1.w;
       }
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(s_tile + j * kRowStride + 8 * g + 4 * h);
-        const float4 a1 = *reinterpret_cast<const float4 *>(s_tile + (32 + j) * kRowStride + 8 * g + 4 * h);
+        const float4 a0 = *reinterpret_cast<const float4 *>(s_tile + (2 * g + h) * 256 + 4 * j);
+        const float4 a1 = *reinterpret_cast<const float4 *>(s_tile + (2 * g + h) * 256 + 4 * (32 + j));
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qf[g].x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qf[g].x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qf[g].y, acc0, 0, 0, 0);
@@ -278,20 +277,25 @@ __global__ void __launch_bounds__(256, VI_FILTER_OCC) filter_kernel(FilterArgs a
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
       }
       if (!(a.xmode & 2u)) {
-        // the two smallest of this lane's 32 values, element index in the low bits
-        float bm1 = INFINITY, bm2 = INFINITY;
+        // the four smallest of this lane's 32 values, element index in the low bits
+        float bm1 = INFINITY, bm2 = INFINITY, bm3 = INFINITY, bm4 = INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = pack_idx(acc0[r], (uint32_t)r);
+          bm4 = __builtin_amdgcn_fmed3f(bm3, bm4, p);
+          bm3 = __builtin_amdgcn_fmed3f(bm2, bm3, p);
           bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
           bm1 = fminf(bm1, p);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = pack_idx(acc1[r], 16u + (uint32_t)r);
+          bm4 = __builtin_amdgcn_fmed3f(bm3, bm4, p);
+          bm3 = __builtin_amdgcn_fmed3f(bm2, bm3, p);
           bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
           bm1 = fminf(bm1, p);
         }
+        if (qlive) a.brec[(size_t)bi + 2u * blk] = make_float4(bm1, bm2, bm3, bm4);
         // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
         const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
         {
@@ -308,9 +312,14 @@ __global__ void __launch_bounds__(256, VI_FILTER_OCC) filter_kernel(FilterArgs a
         }
       }
     }
-    if (!(a.xmode & 4u)) __syncthreads();  // every wave is done reading the tile
-    if (more) stage_write<NG>(stage, s_tile);
-    if (!(a.xmode & 4u)) __syncthreads();  // next tile visible
+    if (NBUF == 1) {
+      __syncthreads();  // every wave is done reading the tile
+      if (more)
+        tile_dma<NG>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+                     a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                     // next tile visible; this tile free to be overwritten
   }
   if (qlive) {
     const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
@@ -328,13 +337,15 @@ struct SelectCommon {
   const float4 *blocks;
   const float4 *gval;
   const uint4 *gpos;
+  const float4 *brec;
   float gamma, e_scale, xmax2;
-  unsigned long long *dbg;  // [6] exact re-evaluations, [7] whole-group re-evaluations
+  unsigned long long *dbg;  // [6] exact re-evaluations, [7] block records consulted
 };
 
 // the query's probes, one per lane r < P
 struct ProbeRegs {
-  uint32_t rel, ng;   // first record / number of records of the probe
+  uint32_t rel, ng;   // first group record (relative to the query's) / number of group records of the probe
+  uint32_t boff;      // first block record of the probe (absolute)
   uint32_t len, fb;   // list length and first block
   uint32_t segb;      // blocks per segment
   uint32_t g;         // candidate-order rank (shard visiting order)
@@ -363,38 +374,55 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
   return acc;
 }
 
-// One wave: top-K of query q under (exact distance, (g << 26) | position) from its G records at gbase.
+// vector (within its 64-vector block) of element e of a lane-block: lane half hh owns rows (r&3)+8(r>>2)+4hh of
+// the 32-row tile e>>4, r = e & 15 (MFMA 32x32 accumulator layout)
+__device__ __forceinline__ uint32_t element_vector(uint32_t e, uint32_t hh) {
+  const uint32_t r = e & 15u;
+  return 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2) + 4u * hh;
+}
+
+constexpr uint32_t kPickCap = 256;     // listed vectors waiting for their exact distance (per wave)
+constexpr uint32_t kConsultCap = 128;  // block records waiting to be consulted (per wave)
+constexpr uint32_t kBlkBits = 20;      // consult key = (probe rank << 21) | (block << 1) | lane half
+
+// One wave: top-K of query q under (exact distance, (g << 26) | position) from its G group records at gbase.
 // Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick,
-                                            WaveTopK &sel) {
-  // ---- stage 1: threshold (*) from the K-th smallest recorded value ----
-  float thr = INFINITY;
-  {
-    const float *vals = reinterpret_cast<const float *>(c.gval + gbase);
-    const uint32_t n4 = 4u * G;
-    WaveTopK s1;
-    s1.init();
-    for (uint32_t base = 0; base < n4; base += kWave) {
-      const uint32_t i = base + lane;
-      const bool live = i < n4;
-      s1.offer(live ? vals[i] : INFINITY, live ? i : kNoPos, (int)K);
-    }
-    const float mk = n4 >= K ? readlane_f(s1.d, (int)K - 1) : INFINITY;
-    if (mk < 1.0e37f) {
-      float qn = 0.0f;
-      for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
+                                            uint32_t *consult, WaveTopK &sel) {
+  const uint64_t below = (1ull << lane) - 1ull;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  float qn = 0.0f;
+  for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
-      const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
-      const float scale = fmaxf(mk + qn, 0.0f) + E;
-      thr = mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  auto threshold_of = [&](float mk) {  // (*) ; anything non-finite or huge means "no bound"
+    if (!(mk < 1.0e37f)) return INFINITY;
+    const float scale = fmaxf(mk + qn, 0.0f) + E;
+    return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+  };
+  // group gidx -> probe rank, segment, lane half (lane-local)
+  auto locate = [&](uint32_t gidx, bool live, uint32_t &r, uint32_t &seg, uint32_t &hh) {
+    r = 0;
+    for (uint32_t rr = 0; rr < P; ++rr) {
+      const uint32_t rel = readlane_u(pr.rel, (int)rr), ng = readlane_u(pr.ng, (int)rr);
+      if (live && gidx >= rel && gidx < rel + ng) r = rr;
     }
-  }
-  // ---- stage 2: exact re-evaluation of what can be at or below thr ----
+    const uint32_t local = gidx - (uint32_t)__shfl((int)pr.rel, (int)r);
+    seg = local >> 1;
+    hh = local & 1u;
+  };
+  uint32_t npick = 0, ncons = 0, n_exact = 0, n_consult = 0;
+  WaveTopK s1;
+  // block records waiting in `consult`; mode 0 = their values refine the threshold, mode 1 = stage 2
+  float thr = INFINITY;
   sel.init();
   const float *qrow = c.Q + (size_t)q * c.dim;
-  uint32_t n_exact = 0, n_full = 0;
   auto exact_offer = [&](bool live, uint32_t r, uint32_t pos) {  // one (probe rank, position) per lane
     const uint32_t fb = (uint32_t)__shfl((int)pr.fb, (int)r);
     const uint32_t g = (uint32_t)__shfl((int)pr.g, (int)r);
@@ -405,8 +433,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     n_exact += (uint32_t)__popcll(__ballot(live));
     sel.offer(d, live ? ((g << kPosBits) | pos) : kNoPos, (int)K);
   };
-  uint32_t npick = 0;
-  auto drain = [&]() {
+  auto drain_pick = [&]() {
     while (npick > 0) {
       const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
       npick -= cnt;
@@ -415,16 +442,120 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       exact_offer(live, ck >> kPosBits, ck & kPosMask);
     }
   };
+  auto push_single = [&](bool want, uint32_t r, uint32_t pos) {  // every lane calls
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (npick + cnt > kPickCap) drain_pick();
+    if (want) pick[npick + (uint32_t)__popcll(m & below)] = (r << kPosBits) | pos;
+    npick += cnt;
+    lds_sync();
+  };
+  // a whole lane-block: 32 lanes, one vector each (requests are rare: one at a time)
+  const int sub = lane & 31;
+  auto lane_blocks = [&](bool want, uint32_t r, uint32_t blk, uint32_t hh) {
+    uint64_t m = __ballot(want);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint32_t rr = readlane_u(r, src), bb = readlane_u(blk, src), h2 = readlane_u(hh, src);
+      exact_offer(lane < 32, rr, bb * kWave + element_vector((uint32_t)sub, h2));
+    }
+  };
+  auto drain_consult = [&](int mode) {
+    while (ncons > 0) {
+      const uint32_t cnt = ncons >= (uint32_t)kWave ? (uint32_t)kWave : ncons;
+      ncons -= cnt;
+      const bool live = (uint32_t)lane < cnt;
+      const uint32_t ck = live ? consult[ncons + lane] : 0u;
+      const uint32_t r = ck >> (kBlkBits + 1), blk = (ck >> 1) & ((1u << kBlkBits) - 1u), hh = ck & 1u;
+      const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)r);
+      float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      if (live) B = c.brec[(size_t)boff + 2u * blk + hh];
+      if (mode == 0) {
+        s1.offer(B.x, live ? 0u : kNoPos, (int)K);
+        s1.offer(B.y, live ? 1u : kNoPos, (int)K);
+        s1.offer(B.z, live ? 2u : kNoPos, (int)K);
+        s1.offer(B.w, live ? 3u : kNoPos, (int)K);
+      } else {
+        n_consult += cnt;
+        const bool whole = live && B.w <= thr;  // rows missing from the record are only known to be >= b4
+        const float bv[3] = {B.x, B.y, B.z};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          push_single(live && !whole && bv[i] <= thr, r, blk * kWave + element_vector(__float_as_uint(bv[i]) & 31u, hh));
+        lane_blocks(whole, r, blk, hh);
+      }
+    }
+  };
+  auto push_consult = [&](bool want, uint32_t r, uint32_t blk, uint32_t hh, int mode) {  // every lane calls
+    const uint64_t m = __ballot(want);
+    if (!m) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (ncons + cnt > kConsultCap) drain_consult(mode);
+    if (want) consult[ncons + (uint32_t)__popcll(m & below)] = (r << (kBlkBits + 1)) | (blk << 1) | hh;
+    ncons += cnt;
+    lds_sync();
+  };
+  // every block record of the groups flagged `full`
+  auto consult_groups = [&](bool full, uint32_t r, uint32_t seg, uint32_t hh, int mode) {
+    uint64_t m = __ballot(full);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint32_t rr = readlane_u(r, src), sg = readlane_u(seg, src), h2 = readlane_u(hh, src);
+      const uint32_t segb = readlane_u(pr.segb, (int)rr), ln = readlane_u(pr.len, (int)rr);
+      const uint32_t nblk = (ln + kWave - 1) / kWave;
+      const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
+      for (uint32_t b = bs; b < be; b += kWave) push_consult(b + lane < be, rr, b + lane, h2, mode);
+    }
+  };
+
+  // ---- stage 1a: threshold (*) from the K-th smallest value of the group records ----
+  bool any_full = false;
+  {
+    const float *vals = reinterpret_cast<const float *>(c.gval + gbase);
+    const uint32_t n4 = 4u * G;
+    s1.init();
+    for (uint32_t base = 0; base < n4; base += kWave) {
+      const uint32_t i = base + lane;
+      const bool live = i < n4;
+      s1.offer(live ? vals[i] : INFINITY, live ? i : kNoPos, (int)K);
+    }
+    thr = threshold_of(readlane_f(s1.d, (int)K - 1));
+    for (uint32_t base = 0; base < n4; base += kWave) {  // is any group's 4th value at or below it?
+      const uint32_t i = base + lane;
+      any_full = any_full || __ballot(i < n4 && (i & 3u) == 3u && vals[i] <= thr) != 0ull;
+    }
+  }
+  // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed values and leave the bound
+  //      loose; the block records of those groups list 4 values per 32 vectors: redo the bound with them ----
+  if (any_full) {
+    s1.init();
+    for (uint32_t gb = 0; gb < G; gb += kWave) {
+      const uint32_t gidx = gb + lane;
+      const bool live = gidx < G;
+      uint32_t r, seg, hh;
+      locate(gidx, live, r, seg, hh);
+      float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      if (live) T = c.gval[gbase + gidx];
+      const bool full = live && T.w <= thr;
+      const bool own = live && !full;  // groups that keep their own listed values
+      s1.offer(own ? T.x : INFINITY, own ? 0u : kNoPos, (int)K);
+      s1.offer(own ? T.y : INFINITY, own ? 1u : kNoPos, (int)K);
+      s1.offer(own ? T.z : INFINITY, own ? 2u : kNoPos, (int)K);
+      s1.offer(own ? T.w : INFINITY, own ? 3u : kNoPos, (int)K);
+      consult_groups(full, r, seg, hh, 0);
+    }
+    drain_consult(0);
+    thr = fminf(thr, threshold_of(readlane_f(s1.d, (int)K - 1)));
+  }
+  // ---- stage 2: exact re-evaluation of what can be at or below thr ----
   for (uint32_t gb = 0; gb < G; gb += kWave) {
     const uint32_t gidx = gb + lane;
     const bool live = gidx < G;
-    uint32_t r = 0;
-    for (uint32_t rr = 0; rr < P; ++rr) {
-      const uint32_t rel = readlane_u(pr.rel, (int)rr), ng = readlane_u(pr.ng, (int)rr);
-      if (live && gidx >= rel && gidx < rel + ng) r = rr;
-    }
-    const uint32_t local = gidx - (uint32_t)__shfl((int)pr.rel, (int)r);
-    const uint32_t seg = local >> 1, hh = local & 1u;
+    uint32_t r, seg, hh;
+    locate(gidx, live, r, seg, hh);
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
@@ -440,62 +571,32 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       is2[i] = (tp[i] & kB2Flag) != 0u;
       blk[i] = (tp[i] & kPosMask) >> 6;
     }
-    // listed vectors (a block's smallest, unless its lane-block is re-evaluated anyway)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      // a listed smallest-of-its-block is evaluated directly unless that block's record is consulted anyway
       bool single = pass[i] && !is2[i];
 #pragma unroll
       for (int jx = 0; jx < 3; ++jx)
         if (jx != i && pass[jx] && is2[jx] && blk[jx] == blk[i]) single = false;
-      const uint64_t m = __ballot(single);
-      const uint32_t cntp = (uint32_t)__popcll(m);
-      if (npick + cntp > 128u) drain();
-      if (single) pick[npick + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (r << kPosBits) | (tp[i] & kPosMask);
-      npick += cntp;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      push_single(single, r, tp[i] & kPosMask);
+      // a listed second-smallest says nothing about its block's other rows: consult the block record
+      push_consult(pass[i] && is2[i], r, blk[i], hh, 1);
     }
-    // lane-blocks: a listed second-smallest at or below thr says nothing about the block's other rows
-    const int sub = lane & 31, e15 = sub & 15;
-    const uint32_t vrow = 32u * (uint32_t)(sub >> 4) + (uint32_t)(e15 & 3) + 8u * (uint32_t)(e15 >> 2);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      uint64_t m = __ballot(pass[i] && is2[i]);
-      while (m) {
-        const int src = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t rr = readlane_u(r, src), bb = readlane_u(blk[i], src), h2 = readlane_u(hh, src);
-        exact_offer(lane < 32, rr, bb * kWave + vrow + 4u * h2);
-      }
-    }
-    // whole groups: the fourth-smallest listed value is at or below thr
-    uint64_t m = __ballot(full);
-    while (m) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const uint32_t rr = readlane_u(r, src), sg = readlane_u(seg, src), h2 = readlane_u(hh, src);
-      const uint32_t segb = readlane_u(pr.segb, (int)rr), ln = readlane_u(pr.len, (int)rr);
-      const uint32_t nblk = (ln + kWave - 1) / kWave;
-      const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
-      n_full++;
-      for (uint32_t b = bs; b < be; b += 2) {  // two blocks per pass: lanes 0-31 / 32-63
-        const uint32_t bb = b + (uint32_t)(lane >> 5);
-        exact_offer(bb < be, rr, bb * kWave + vrow + 4u * h2);
-      }
-    }
+    // the fourth-smallest listed value is at or below thr: consult every block record of the group
+    consult_groups(full, r, seg, hh, 1);
   }
-  drain();
+  drain_consult(1);
+  drain_pick();
   if (c.dbg && lane == 0) {
     atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
-    atomicAdd(&c.dbg[7], (unsigned long long)n_full);
+    atomicAdd(&c.dbg[7], (unsigned long long)n_consult);
   }
 }
 
 struct SelectArgs {
   SelectCommon c;
   uint32_t nq, P, k, segb0;
-  const uint32_t *qoff, *qtot, *rel;
+  const uint32_t *qoff, *qtot, *rel, *qoffb, *relb;
   const uint32_t *probes, *gorder, *first_block, *list_len;
   const uint64_t *ext_ids;
   float *D;
@@ -506,17 +607,18 @@ struct SelectArgs {
 
 // one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
-  __shared__ uint32_t s_pick[4][128];
+  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  ProbeRegs pr{0u, 0u, 0u, 0u, 1u, kNoPos};
+  ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, kNoPos};
   uint32_t mylist = kNoPos;
   if ((uint32_t)lane < a.P) {
     const size_t s = (size_t)q * a.P + lane;
     mylist = a.probes[s];
     pr.g = a.gorder[s];
     pr.rel = a.rel[s];
+    pr.boff = a.qoffb[q] + a.relb[s];
     if (mylist != kNoPos) {
       pr.len = a.list_len[mylist];
       pr.fb = a.first_block[mylist];
@@ -524,7 +626,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
     }
   }
   WaveTopK sel;
-  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], sel);
+  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_consult[wave], sel);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
   const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
   uint32_t r = 0;
@@ -555,7 +657,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
 
 struct CoarseSelectArgs {
   SelectCommon c;  // blocks = centroid table
-  uint32_t nq, P, nlists, segb, recs;  // recs = records per query
+  uint32_t nq, P, nlists, segb, recs, brecs;  // recs / brecs = group / block records per query
   const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt;
 };
@@ -563,14 +665,14 @@ struct CoarseSelectArgs {
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
 // sort, ivf_index.rs:205-220), then shard visiting order + histogram as in coarse_merge_kernel
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
-  __shared__ uint32_t s_pick[4][128];
+  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
-  ProbeRegs pr{0u, 0u, 0u, 0u, 1u, 0u};
-  if (lane == 0) { pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb; }
+  ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, 0u};
+  if (lane == 0) { pr.ng = a.recs; pr.boff = q * a.brecs; pr.len = a.nlists; pr.segb = a.segb; }
   WaveTopK sel;
-  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], sel);
+  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], sel);
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
@@ -584,7 +686,9 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
 template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, hipStream_t st) {
   if (nitems == 0) return VI_OK;
-  hipLaunchKernelGGL((filter_kernel<NG>), dim3(nitems), dim3(256), 0, st, a);
+  static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
+  if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1>), dim3(nitems), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((filter_kernel<NG, 2>), dim3(nitems), dim3(256), 0, st, a);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -608,6 +712,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
   c.gval = (const float4 *)ix.ws.gval.p; c.gpos = (const uint4 *)ix.ws.gpos.p;
+  c.brec = (const float4 *)ix.ws.brec.p;
   c.gamma = (float)((ix.dim + 2.0) * u);
   c.e_scale = (float)((ix.dim + 2.0) * u + 1.01 * std::ldexp(1.0, -18));
   c.xmax2 = xmax2;
@@ -651,7 +756,7 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
     VI_HIP(hipGetLastError());
     const uint64_t npad = cslots - ix->nlists;
     if (npad) {
-      std::vector<float> inf(npad, INFINITY);
+      std::vector<float> inf(npad, kBig);
       VI_HIP(hipMemcpyAsync(ix->cent_xnorm.p + ix->nlists, inf.data(), npad * 4, hipMemcpyHostToDevice, ix->stream));
     }
   }
@@ -681,7 +786,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   const uint32_t segb0 = 4;
   uint32_t segb;
   const uint32_t nseg = list_segments((uint32_t)nlists, segb0, &segb);
-  const uint32_t recs = 2u * nseg;
+  const uint32_t recs = 2u * nseg, brecs = 2u * (uint32_t)ix.centroids.nblocks;
   const uint32_t ngroups = (uint32_t)((nq + kGroupQ - 1) / kGroupQ);
   const uint32_t h_seg[2] = {0u, (uint32_t)nq}, h_item[2] = {0u, ngroups * nseg};
   VI_TRY(ws.c_seg.reserve(2));
@@ -689,6 +794,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.c_pairs.reserve(nq));
   VI_TRY(ws.gval.reserve(nq * recs * 4));
   VI_TRY(ws.gpos.reserve(nq * recs * 4));
+  VI_TRY(ws.brec.reserve(nq * brecs * 4));
   VI_TRY(ws.stats.reserve(8));
   VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
   VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
@@ -699,12 +805,13 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
     a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
-    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p;
+    a.qoffb = nullptr; a.relb = nullptr; a.brec_stride = brecs;
+    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, st));
   }
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
-                       (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
+                       (uint32_t)nlists, segb, recs, brecs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
                        ws.cnt.p};
     a.c.dbg = nullptr;
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
@@ -718,7 +825,7 @@ bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint
   if (force && *force == '0') return false;
   if (ix.order != VI_ORDER_SCALAR || ix.dim > 128 || (ix.dim & 3) || ix.dim < 4) return false;
   if (k > kMaxSelect || P > kMaxSelect || P < 1) return false;
-  if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // record position < 2^26
+  if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // record position < 2^26, block < 2^20
   if (!(ix.xmax2 < 1.0e30f) || !(ix.cent_xmax2 < 1.0e30f)) return false;  // norms must stay far below kBig
   if (force && *force == '1') return true;
   // worth it when query tiles fill up: on average >= 8 queries per probed list
@@ -747,19 +854,24 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
+  VI_TRY(ws.pair_relb.reserve(nq * P));
+  VI_TRY(ws.qtotb.reserve(nq));
+  VI_TRY(ws.qoffb.reserve(nq + 1));
   hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
-                     ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p);
-  hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
+                     ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p);
+  hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, ws.qtotb.p, (uint32_t)nq, ws.qoff.p,
+                     ws.qoffb.p);
   VI_HIP(hipGetLastError());
-  uint64_t hstats[5];
+  uint64_t hstats[6];
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st, true));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];
-  const uint64_t nrec = hstats[4];
-  if (nrec >= (1ull << 31)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
+  const uint64_t nrec = hstats[4], nbrec = hstats[5];
+  if (nrec >= (1ull << 31) || nbrec >= (1ull << 32)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
   VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec) * 4));
+  VI_TRY(ws.brec.reserve(std::max<uint64_t>(1, nbrec) * 4));
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
   // ---- 3. rank on the matrix cores ----
   {
@@ -768,7 +880,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
     a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
-    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p;
+    a.qoffb = ws.qoffb.p; a.relb = ws.pair_relb.p; a.brec_stride = 0;
+    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
     VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], st));
   }
@@ -776,7 +889,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 4. select ----
   {
     SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2), (uint32_t)nq, P, (uint32_t)k, segb0,
-                 ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
+                 ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.qoffb.p, ws.pair_relb.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());

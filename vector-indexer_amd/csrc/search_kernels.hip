@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   uint32_t seg = 0, item = 0, run = 0;
-  unsigned long long vec = 0, tb = 0, rec = 0;
+  unsigned long long vec = 0, tb = 0, rec = 0, brc = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint32_t c = list_count(cnt, l);
     uint32_t segb;
@@ -396,9 +396,11 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     vec += (unsigned long long)c * list_len[l];
     tb += (unsigned long long)((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
     rec += 2ull * c * ns;
+    brc += 2ull * c * ((list_len[l] + 63) / 64);
   }
   atomicAdd((unsigned long long *)&stats[3], tb);   // (query group, block) tiles
-  atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: records = 2 per (pair, segment)
+  atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
+  atomicAdd((unsigned long long *)&stats[5], brc);  // MFMA path: block records = 2 per (pair, block)
   s_seg[t] = seg; s_item[t] = item; s_run[t] = run; s_vec[t] = vec;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -1137,7 +1139,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 // Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[5], hipStream_t st, bool histogram_done) {
+                          uint64_t hstats[6], hipStream_t st, bool histogram_done) {
   SearchWorkspace &ws = ix.ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1159,7 +1161,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
                      ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
   VI_HIP(hipGetLastError());
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));
   return VI_OK;
 }
