@@ -113,25 +113,29 @@ __global__ void pair_groups_kernel(const uint32_t *probes, const uint32_t *list_
 // qoff / qoffb = exclusive scans of qtot / qtotb over the queries (one workgroup), [nq] = totals
 __global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, const uint32_t *qtotb, uint32_t nq,
                                                              uint32_t *qoff, uint32_t *qoffb) {
-  __shared__ uint32_t s[1024], sb[1024];
+  __shared__ uint32_t s[16], sb[16];
   const uint32_t t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
   const uint32_t per = (nq + 1023) / 1024;
   const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
   uint32_t sum = 0, sumb = 0;
   for (uint32_t i = beg; i < end; ++i) { sum += qtot[i]; sumb += qtotb[i]; }
-  s[t] = sum;
-  sb[t] = sumb;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t a = t >= off ? s[t - off] : 0u, b = t >= off ? sb[t - off] : 0u;
-    __syncthreads();
-    s[t] += a;
-    sb[t] += b;
-    __syncthreads();
+  uint32_t inc = sum, incb = sumb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = (uint32_t)__shfl_up((int)inc, o), y = (uint32_t)__shfl_up((int)incb, o);
+    if (lane >= o) { inc += x; incb += y; }
   }
-  uint32_t run = s[t] - sum, runb = sb[t] - sumb;
+  if (lane == 63) { s[wave] = inc; sb[wave] = incb; }
+  __syncthreads();
+  uint32_t w = 0, wb = 0, tot = 0, totb = 0;
+  for (int i = 0; i < 16; ++i) {
+    if (i < wave) { w += s[i]; wb += sb[i]; }
+    tot += s[i]; totb += sb[i];
+  }
+  uint32_t run = w + inc - sum, runb = wb + incb - sumb;
   for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; qoffb[i] = runb; runb += qtotb[i]; }
-  if (t == 1023) { qoff[nq] = s[1023]; qoffb[nq] = sb[1023]; }
+  if (t == 0) { qoff[nq] = tot; qoffb[nq] = totb; }
 }
 
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
@@ -384,12 +388,13 @@ __device__ __forceinline__ uint32_t element_vector(uint32_t e, uint32_t hh) {
 constexpr uint32_t kPickCap = 256;     // listed vectors waiting for their exact distance (per wave)
 constexpr uint32_t kConsultCap = 128;  // block records waiting to be consulted (per wave)
 constexpr uint32_t kBlkBits = 20;      // consult key = (probe rank << 21) | (block << 1) | lane half
+constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/half) kept in LDS per wave
 
 // One wave: top-K of query q under (exact distance, (g << 26) | position) from its G group records at gbase.
 // Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick,
-                                            uint32_t *consult, WaveTopK &sel) {
+                                            uint32_t *consult, float4 *tcache, uint32_t *lcache, WaveTopK &sel) {
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -511,41 +516,103 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     }
   };
 
-  // ---- stage 1a: threshold (*) from the K-th smallest value of the group records ----
+  // ---- stage 0: the first 256 group records go to LDS in one round of loads (the three passes below would
+  //      otherwise each pay the global-memory latency per 64 groups) ----
+  {
+    float4 t4[kCacheG / kWave];
+#pragma unroll
+    for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
+      const uint32_t gidx = ch * kWave + lane;
+      t4[ch] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+      if (gidx < G) t4[ch] = c.gval[gbase + gidx];
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
+      const uint32_t gidx = ch * kWave + lane;
+      if (ch * kWave < G) {
+        uint32_t r, seg, hh;
+        locate(gidx, gidx < G, r, seg, hh);
+        tcache[gidx] = t4[ch];
+        lcache[gidx] = r | (seg << 6) | (hh << 13);
+      }
+    }
+    lds_sync();
+  }
+  auto group_values = [&](uint32_t gidx, bool live) {
+    float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (live) T = gidx < kCacheG ? tcache[gidx] : c.gval[gbase + gidx];
+    return T;
+  };
+  auto group_place = [&](uint32_t gidx, bool live, uint32_t &r, uint32_t &seg, uint32_t &hh) {
+    if (gidx - lane < kCacheG) {  // wave-uniform: the whole chunk is cached
+      const uint32_t L = live ? lcache[gidx] : 0u;
+      r = L & 63u; seg = (L >> 6) & 127u; hh = L >> 13;
+    } else {
+      locate(gidx, live, r, seg, hh);
+    }
+  };
+  // ---- stage 1a: threshold (*) from the K-th smallest value of the group records (key = 4*group + slot);
+  //      the groups' smallest values first: they shut the door on most of the others ----
   bool any_full = false;
   {
-    const float *vals = reinterpret_cast<const float *>(c.gval + gbase);
-    const uint32_t n4 = 4u * G;
-    s1.init();
-    for (uint32_t base = 0; base < n4; base += kWave) {
-      const uint32_t i = base + lane;
-      const bool live = i < n4;
-      s1.offer(live ? vals[i] : INFINITY, live ? i : kNoPos, (int)K);
-    }
-    thr = threshold_of(readlane_f(s1.d, (int)K - 1));
-    for (uint32_t base = 0; base < n4; base += kWave) {  // is any group's 4th value at or below it?
-      const uint32_t i = base + lane;
-      any_full = any_full || __ballot(i < n4 && (i & 3u) == 3u && vals[i] <= thr) != 0ull;
-    }
-  }
-  // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed values and leave the bound
-  //      loose; the block records of those groups list 4 values per 32 vectors: redo the bound with them ----
-  if (any_full) {
     s1.init();
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
       const bool live = gidx < G;
+      s1.offer(group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
+    }
+    for (uint32_t gb = 0; gb < G; gb += kWave) {
+      const uint32_t gidx = gb + lane;
+      const bool live = gidx < G;
+      const float4 T = group_values(gidx, live);
+      s1.offer(T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
+      s1.offer(T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
+      s1.offer(T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
+    }
+    thr = threshold_of(readlane_f(s1.d, (int)K - 1));
+    for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
+      const uint32_t gidx = gb + lane;
+      const float4 T = group_values(gidx, gidx < G);
+      any_full = any_full || __ballot(gidx < G && T.w <= thr) != 0ull;
+    }
+  }
+  // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed values and leave the bound
+  //      loose; the block records of those groups list 4 values per 32 vectors.  Their values REPLACE the
+  //      group's own (which are among them, so they must not be counted twice): drop the group's entries from
+  //      the running top-K, then offer its block records ----
+  if (any_full) {
+    {
+      const bool mine = s1.p != kNoPos && (uint32_t)lane < K;  // entries beyond the K-th are not needed
+      const uint32_t g = mine ? (s1.p >> 2) : 0u;
+      const bool drop = mine && group_values(g, true).w <= thr;
+      const bool keep = mine && !drop;
+      const uint64_t km = __ballot(keep);
+      // survivors close ranks: the lane of rank i fetches the i-th surviving entry
+      uint64_t rest = km;
+      int src = 63;
+      const int want = lane;
+      const int nkeep = __popcll(km);
+      // position of the want-th set bit of km (serial over <= K set bits: K <= 64)
+      int seen = 0;
+      for (int b = 0; b < nkeep; ++b) {
+        const int pos = __builtin_ctzll(rest);
+        rest &= rest - 1ull;
+        if (seen == want) src = pos;
+        ++seen;
+      }
+      const float nd = __shfl(s1.d, src);
+      const uint32_t np = (uint32_t)__shfl((int)s1.p, src);
+      s1.d = lane < nkeep ? nd : INFINITY;
+      s1.p = lane < nkeep ? np : kNoPos;
+      s1.thr = readlane_f(s1.d, (int)K - 1);
+      s1.thrp = readlane_u(s1.p, (int)K - 1);
+    }
+    for (uint32_t gb = 0; gb < G; gb += kWave) {
+      const uint32_t gidx = gb + lane;
+      const bool live = gidx < G;
       uint32_t r, seg, hh;
-      locate(gidx, live, r, seg, hh);
-      float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-      if (live) T = c.gval[gbase + gidx];
-      const bool full = live && T.w <= thr;
-      const bool own = live && !full;  // groups that keep their own listed values
-      s1.offer(own ? T.x : INFINITY, own ? 0u : kNoPos, (int)K);
-      s1.offer(own ? T.y : INFINITY, own ? 1u : kNoPos, (int)K);
-      s1.offer(own ? T.z : INFINITY, own ? 2u : kNoPos, (int)K);
-      s1.offer(own ? T.w : INFINITY, own ? 3u : kNoPos, (int)K);
-      consult_groups(full, r, seg, hh, 0);
+      group_place(gidx, live, r, seg, hh);
+      consult_groups(live && group_values(gidx, live).w <= thr, r, seg, hh, 0);
     }
     drain_consult(0);
     thr = fminf(thr, threshold_of(readlane_f(s1.d, (int)K - 1)));
@@ -555,12 +622,13 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t gidx = gb + lane;
     const bool live = gidx < G;
     uint32_t r, seg, hh;
-    locate(gidx, live, r, seg, hh);
+    group_place(gidx, live, r, seg, hh);
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
-    float4 T = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
-    if (live) { T = c.gval[gbase + gidx]; Pp = c.gpos[gbase + gidx]; }
+    const float4 T = group_values(gidx, live);
     const bool full = live && T.w <= thr;
+    // positions are only needed by chunks that list something at or below thr
+    uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
+    if (live && !full && T.x <= thr) Pp = c.gpos[gbase + gidx];
     const float tv[3] = {T.x, T.y, T.z};
     const uint32_t tp[3] = {Pp.x, Pp.y, Pp.z};
     bool pass[3], is2[3];
@@ -607,7 +675,8 @@ struct SelectArgs {
 
 // one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap];
+  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap], s_lcache[4][kCacheG];
+  __shared__ float4 s_tcache[4][kCacheG];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -626,7 +695,8 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
     }
   }
   WaveTopK sel;
-  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_consult[wave], sel);
+  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
+              s_lcache[wave], sel);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
   const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
   uint32_t r = 0;
@@ -660,19 +730,24 @@ struct CoarseSelectArgs {
   uint32_t nq, P, nlists, segb, recs, brecs;  // recs / brecs = group / block records per query
   const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt;
+  // record counts of the list phase (what pair_groups_kernel computes otherwise)
+  uint32_t list_segb0;
+  uint32_t *rel, *qtot, *relb, *qtotb;
 };
 
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
 // sort, ivf_index.rs:205-220), then shard visiting order + histogram as in coarse_merge_kernel
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap];
+  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap], s_lcache[4][kCacheG];
+  __shared__ float4 s_tcache[4][kCacheG];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
   ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, 0u};
   if (lane == 0) { pr.ng = a.recs; pr.boff = q * a.brecs; pr.len = a.nlists; pr.segb = a.segb; }
   WaveTopK sel;
-  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], sel);
+  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
+              s_lcache[wave], sel);
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
@@ -680,6 +755,29 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
     if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+  }
+  // records of the list phase: 2 per (probe, segment) and 2 per (probe, block); query_offsets_kernel turns the
+  // per-query totals into offsets
+  uint32_t ng = 0, nb = 0;
+  if (mylist != kNoPos) {
+    const uint32_t len = a.list_len[mylist];
+    uint32_t sb;
+    ng = 2u * list_segments(len, a.list_segb0, &sb);
+    nb = 2u * ((len + 63u) / 64u);
+  }
+  uint32_t ig = ng, ib = nb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = (uint32_t)__shfl_up((int)ig, o), y = (uint32_t)__shfl_up((int)ib, o);
+    if (lane >= o) { ig += x; ib += y; }
+  }
+  if ((uint32_t)lane < a.P) {
+    a.rel[(size_t)q * a.P + lane] = ig - ng;
+    a.relb[(size_t)q * a.P + lane] = ib - nb;
+  }
+  if (lane == 63) {
+    a.qtot[q] = ig;
+    a.qtotb[q] = ib;
   }
 }
 
@@ -774,7 +872,8 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
 
 // coarse quantizer on the matrix cores: the centroid table is one "list" probed by every query.
 // Leaves probes / gorder and the per-list histogram (ws.cnt) behind, like stage_coarse.
-vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
+vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, uint32_t list_segb0,
+                              hipStream_t st) {
   SearchWorkspace &ws = ix.ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
@@ -812,7 +911,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
                        (uint32_t)nlists, segb, recs, brecs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
-                       ws.cnt.p};
+                       ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p};
     a.c.dbg = nullptr;
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
@@ -840,15 +939,6 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   const uint32_t dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   (void)K;
-  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
-  // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram ----
-  {
-    const char *cf = getenv("VI_COARSE_FILTER");
-    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) VI_TRY(stage_coarse_filter(ix, Qd, nq, P, st));
-    else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
-  }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
-  // ---- 2. group all (query, probe) pairs by list; record offsets per pair ----
   const char *sb = getenv("VI_FILTER_SEGB");
   const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 16u;  // <= 1024 vectors per work item
   VI_TRY(ws.pair_rel.reserve(nq * P));
@@ -857,11 +947,23 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.pair_relb.reserve(nq * P));
   VI_TRY(ws.qtotb.reserve(nq));
   VI_TRY(ws.qoffb.reserve(nq + 1));
-  hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
-                     ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p);
-  hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, ws.qtotb.p, (uint32_t)nq, ws.qoff.p,
-                     ws.qoffb.p);
-  VI_HIP(hipGetLastError());
+  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+  // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
+  {
+    const char *cf = getenv("VI_COARSE_FILTER");
+    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) {
+      VI_TRY(stage_coarse_filter(ix, Qd, nq, P, segb0, st));
+    } else {
+      VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+      hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
+                         ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p);
+    }
+    hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, ws.qtotb.p, (uint32_t)nq, ws.qoff.p,
+                       ws.qoffb.p);
+    VI_HIP(hipGetLastError());
+  }
+  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
+  // ---- 2. group all (query, probe) pairs by list ----
   uint64_t hstats[6];
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st, true));
   stt.scanned_vectors = hstats[0];

@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 //   item_start   Σ ceil(cnt/QG) * nseg      (scan work items)
 //   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
 // stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
+static_assert(kSubBins == 8, "group_scan_kernel reads a list's sub-bin counters as two uint4");
 __device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l) {
   uint32_t c = 0;
 #pragma unroll
@@ -379,55 +380,78 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
                                                           uint32_t nlists, uint32_t qg, uint32_t segb0,
                                                           uint32_t *seg_start, uint32_t *item_start,
                                                           uint32_t *segrun_start, uint32_t *cursor, uint64_t *stats) {
-  __shared__ uint32_t s_seg[1024], s_item[1024], s_run[1024];
-  __shared__ unsigned long long s_vec[1024];
+  __shared__ uint32_t s_seg[16], s_item[16], s_run[16];
   const uint32_t t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
+  const uint4 *cnt4 = reinterpret_cast<const uint4 *>(cnt);  // kSubBins == 8: two uint4 per list
   uint32_t seg = 0, item = 0, run = 0;
   unsigned long long vec = 0, tb = 0, rec = 0, brc = 0;
   for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = list_count(cnt, l);
+    const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
+    const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+    const uint32_t len = list_len[l];
     uint32_t segb;
-    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
+    const uint32_t ns = list_segments(len, segb0, &segb);
+    const uint32_t chunks = (c + qg - 1) / qg;
     seg += c;
-    item += ((c + qg - 1) / qg) * ns;
+    item += chunks * ns;
     run += ns > 1 ? c * ns : 0u;
-    vec += (unsigned long long)c * list_len[l];
-    tb += (unsigned long long)((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
+    vec += (unsigned long long)c * len;
+    tb += (unsigned long long)chunks * ((len + 63) / 64);
     rec += 2ull * c * ns;
-    brc += 2ull * c * ((list_len[l] + 63) / 64);
+    brc += 2ull * c * ((len + 63) / 64);
   }
-  atomicAdd((unsigned long long *)&stats[3], tb);   // (query group, block) tiles
-  atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
-  atomicAdd((unsigned long long *)&stats[5], brc);  // MFMA path: block records = 2 per (pair, block)
-  s_seg[t] = seg; s_item[t] = item; s_run[t] = run; s_vec[t] = vec;
+  // inclusive scans across the wave, then across the 16 waves
+  uint32_t iseg = seg, iitem = item, irun = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = (uint32_t)__shfl_up((int)iseg, o), b = (uint32_t)__shfl_up((int)iitem, o);
+    const uint32_t r = (uint32_t)__shfl_up((int)irun, o);
+    if (lane >= o) { iseg += a; iitem += b; irun += r; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vec += __shfl_xor(vec, o);
+    tb += __shfl_xor(tb, o);
+    rec += __shfl_xor(rec, o);
+    brc += __shfl_xor(brc, o);
+  }
+  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; }
+  if (lane == 0) {
+    atomicAdd((unsigned long long *)&stats[0], vec);  // scanned vectors
+    atomicAdd((unsigned long long *)&stats[3], tb);   // (query group, block) tiles
+    atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
+    atomicAdd((unsigned long long *)&stats[5], brc);  // MFMA path: block records = 2 per (pair, block)
+  }
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t a = 0, b = 0, r = 0;
-    unsigned long long c = 0;
-    if (t >= off) { a = s_seg[t - off]; b = s_item[t - off]; r = s_run[t - off]; c = s_vec[t - off]; }
-    __syncthreads();
-    s_seg[t] += a; s_item[t] += b; s_run[t] += r; s_vec[t] += c;
-    __syncthreads();
+  uint32_t wseg = 0, witem = 0, wrun = 0, tseg = 0, titem = 0, trun = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; }
+    tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w];
   }
-  uint32_t rs = s_seg[t] - seg, ri = s_item[t] - item, rr = s_run[t] - run;
+  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run;
+  uint4 *cur4 = reinterpret_cast<uint4 *>(cursor);
   for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = list_count(cnt, l);
+    const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
+    const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
-    uint32_t sub = rs;  // each sub-bin scatters into its own slice of the list's segment
-    for (uint32_t s = 0; s < kSubBins; ++s) { cursor[l * kSubBins + s] = sub; sub += cnt[l * kSubBins + s]; }
+    // each sub-bin scatters into its own slice of the list's segment
+    uint4 u0, u1;
+    u0.x = rs; u0.y = u0.x + c0.x; u0.z = u0.y + c0.y; u0.w = u0.z + c0.z;
+    u1.x = u0.w + c0.w; u1.y = u1.x + c1.x; u1.z = u1.y + c1.y; u1.w = u1.z + c1.z;
+    cur4[2 * l] = u0; cur4[2 * l + 1] = u1;
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
   }
-  if (t == 1023) {
-    seg_start[nlists] = s_seg[1023];
-    item_start[nlists] = s_item[1023];
-    segrun_start[nlists] = s_run[1023];
-    stats[0] = s_vec[1023];
-    stats[1] = s_item[1023];
-    stats[2] = s_run[1023];
+  if (t == 0) {
+    seg_start[nlists] = tseg;
+    item_start[nlists] = titem;
+    segrun_start[nlists] = trun;
+    stats[1] = titem;
+    stats[2] = trun;
   }
 }
 
@@ -992,20 +1016,23 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(nq * P));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
                      ws.cnt.p + nlists * kSubBins, ws.stats.p);
   VI_HIP(hipGetLastError());
+  // exact work-item / segment-run counts size the scan grid and its scratch; the host waits for them while the
+  // scatter runs
+  uint64_t hstats[3] = {0, 0, 0};
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipEventRecord(ix.ev[5], st));
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
                        ix.list_len.p, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
     VI_HIP(hipGetLastError());
   }
-  // exact work-item / segment-run counts size the scan grid and its scratch
-  uint64_t hstats[3] = {0, 0, 0};
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
+  VI_HIP(hipEventSynchronize(ix.ev[5]));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   const uint64_t nsegruns = hstats[2];
@@ -1158,11 +1185,14 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
                      ws.cnt.p + nlists * kSubBins, ws.stats.p);
+  VI_HIP(hipGetLastError());
+  // the host waits for the counts (grid size, scratch) while the scatter runs
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipEventRecord(ix.ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
                      ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
   VI_HIP(hipGetLastError());
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
+  VI_HIP(hipEventSynchronize(ix.ev[5]));
   return VI_OK;
 }
 
