@@ -240,6 +240,7 @@ def test_mfma_filter_duplicates_reevaluate_whole_groups(tmp_path, monkeypatch):
     orc, gpu = oracle_and_gpu(tmp_path, X, nlist=4)
     Q = np.concatenate([base, rng.standard_normal((60, 16)).astype(np.float32)])
     monkeypatch.setenv("VI_FILTER", "1")
+    monkeypatch.setenv("VI_FILTER_STATS", "1")
     gpu.enable_timing(True)
     check_parity(orc, gpu, Q, 10, 4)
     st = gpu.last_stats()

@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   }
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
-  uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos, P3 = kNoPos;
+  uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos;  // (T3 only guards: its position is never needed)
   uint32_t bi = 0;  // this lane's first block record (record counts are checked < 2^32 on the host)
   if (qlive) bi = (a.qoffb ? a.qoffb[qid] + a.relb[slot] : slot * a.brec_stride) + (uint32_t)h;
 
@@ -306,13 +306,13 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
           const uint32_t e = __float_as_uint(bm1) & 31u, r = e & 15u;
           float v = bm1;
           uint32_t pos = pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2);
-          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) VI_INS(T3, P3)
+          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) T3 = fminf(T3, v);
         }
         {
           const uint32_t e = __float_as_uint(bm2) & 31u, r = e & 15u;
           float v = bm2;
           uint32_t pos = (pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2)) | kB2Flag;
-          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) VI_INS(T3, P3)
+          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) T3 = fminf(T3, v);
         }
       }
     }
@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   if (qlive) {
     const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
     a.gval[gi] = make_float4(T0, T1, T2, T3);
-    a.gpos[gi] = make_uint4(P0, P1, P2, P3);
+    // the 4th position is never needed (T3 only guards): its slot carries where the record belongs
+    a.gpos[gi] = make_uint4(P0, P1, P2, (slot - qid * a.P) | (seg << 6) | ((uint32_t)h << 13));
   }
 }
 
@@ -411,17 +412,6 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const float scale = fmaxf(mk + qn, 0.0f) + E;
     return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
   };
-  // group gidx -> probe rank, segment, lane half (lane-local)
-  auto locate = [&](uint32_t gidx, bool live, uint32_t &r, uint32_t &seg, uint32_t &hh) {
-    r = 0;
-    for (uint32_t rr = 0; rr < P; ++rr) {
-      const uint32_t rel = readlane_u(pr.rel, (int)rr), ng = readlane_u(pr.ng, (int)rr);
-      if (live && gidx >= rel && gidx < rel + ng) r = rr;
-    }
-    const uint32_t local = gidx - (uint32_t)__shfl((int)pr.rel, (int)r);
-    seg = local >> 1;
-    hh = local & 1u;
-  };
   uint32_t npick = 0, ncons = 0, n_exact = 0, n_consult = 0;
   WaveTopK s1;
   // block records waiting in `consult`; mode 0 = their values refine the threshold, mode 1 = stage 2
@@ -436,7 +426,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     float d = INFINITY;
     if (live) d = exact_pair(qrow, c.blocks + ((size_t)(fb + pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
     n_exact += (uint32_t)__popcll(__ballot(live));
-    sel.offer(d, live ? ((g << kPosBits) | pos) : kNoPos, (int)K);
+    sel.offer_bulk(d, live ? ((g << kPosBits) | pos) : kNoPos, (int)K);
   };
   auto drain_pick = [&]() {
     while (npick > 0) {
@@ -478,10 +468,10 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
       if (live) B = c.brec[(size_t)boff + 2u * blk + hh];
       if (mode == 0) {
-        s1.offer(B.x, live ? 0u : kNoPos, (int)K);
-        s1.offer(B.y, live ? 1u : kNoPos, (int)K);
-        s1.offer(B.z, live ? 2u : kNoPos, (int)K);
-        s1.offer(B.w, live ? 3u : kNoPos, (int)K);
+        s1.offer_bulk(B.x, live ? 0u : kNoPos, (int)K);
+        s1.offer_bulk(B.y, live ? 1u : kNoPos, (int)K);
+        s1.offer_bulk(B.z, live ? 2u : kNoPos, (int)K);
+        s1.offer_bulk(B.w, live ? 3u : kNoPos, (int)K);
       } else {
         n_consult += cnt;
         const bool whole = live && B.w <= thr;  // rows missing from the record are only known to be >= b4
@@ -526,14 +516,19 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       t4[ch] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
       if (gidx < G) t4[ch] = c.gval[gbase + gidx];
     }
+    uint32_t l4[kCacheG / kWave];
+#pragma unroll
+    for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
+      const uint32_t gidx = ch * kWave + lane;
+      l4[ch] = 0u;
+      if (gidx < G) l4[ch] = c.gpos[gbase + gidx].w;  // probe rank | segment << 6 | lane half << 13
+    }
 #pragma unroll
     for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
       const uint32_t gidx = ch * kWave + lane;
       if (ch * kWave < G) {
-        uint32_t r, seg, hh;
-        locate(gidx, gidx < G, r, seg, hh);
         tcache[gidx] = t4[ch];
-        lcache[gidx] = r | (seg << 6) | (hh << 13);
+        lcache[gidx] = l4[ch];
       }
     }
     lds_sync();
@@ -544,12 +539,9 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     return T;
   };
   auto group_place = [&](uint32_t gidx, bool live, uint32_t &r, uint32_t &seg, uint32_t &hh) {
-    if (gidx - lane < kCacheG) {  // wave-uniform: the whole chunk is cached
-      const uint32_t L = live ? lcache[gidx] : 0u;
-      r = L & 63u; seg = (L >> 6) & 127u; hh = L >> 13;
-    } else {
-      locate(gidx, live, r, seg, hh);
-    }
+    uint32_t L = 0u;
+    if (live) L = gidx < kCacheG ? lcache[gidx] : c.gpos[gbase + gidx].w;
+    r = L & 63u; seg = (L >> 6) & 127u; hh = L >> 13;
   };
   // ---- stage 1a: threshold (*) from the K-th smallest value of the group records (key = 4*group + slot);
   //      the groups' smallest values first: they shut the door on most of the others ----
@@ -559,15 +551,15 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
       const bool live = gidx < G;
-      s1.offer(group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
+      s1.offer_bulk(group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
     }
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
       const bool live = gidx < G;
       const float4 T = group_values(gidx, live);
-      s1.offer(T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
-      s1.offer(T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
-      s1.offer(T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
+      s1.offer_bulk(T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
+      s1.offer_bulk(T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
+      s1.offer_bulk(T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
     }
     thr = threshold_of(readlane_f(s1.d, (int)K - 1));
     for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
@@ -814,7 +806,9 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.gamma = (float)((ix.dim + 2.0) * u);
   c.e_scale = (float)((ix.dim + 2.0) * u + 1.01 * std::ldexp(1.0, -18));
   c.xmax2 = xmax2;
-  c.dbg = (unsigned long long *)ix.ws.stats.p;
+  // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
+  // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
+  c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.ws.stats.p : nullptr;
   return c;
 }
 
@@ -997,7 +991,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
-  if (timing) {
+  if (timing && getenv("VI_FILTER_STATS")) {
     uint64_t dbg[8];
     VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));

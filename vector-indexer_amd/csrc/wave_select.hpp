@@ -71,6 +71,45 @@ struct WaveTopK {
       mask = __ballot(pass) & rest;
     }
   }
+  // ---- bulk variant (select kernels): when more than a few lanes beat entry K-1, one bitonic sort + merge
+  //      (straight-line cross-lane code) replaces that many serial insertions ----
+  static __device__ __forceinline__ void cmpx(float &v, uint32_t &k, int j, bool want_min) {
+    const float pv = __shfl_xor(v, j);
+    const uint32_t pk = (uint32_t)__shfl_xor((int)k, j);
+    const bool p_less = (pv < v) || (pv == v && pk < k);
+    const bool take = want_min == p_less;
+    v = take ? pv : v;
+    k = take ? pk : k;
+  }
+  __device__ __forceinline__ void offer_bulk(float dist, uint32_t pos, int K) {
+    const bool pass = (dist < thr) || (dist == thr && pos < thrp);
+    const uint64_t mask = __ballot(pass);
+    if (!mask) return;
+    if (__popcll(mask) <= 3) { offer(dist, pos, K); return; }
+    const int lane = (int)(threadIdx.x & 63u);
+    float v = pass ? dist : INFINITY;
+    uint32_t k = pass ? pos : kNoPos;
+    // bitonic sort of the 64 incoming pairs, DESCENDING
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        const bool lower = (lane & j) == 0;
+        const bool desc_block = (lane & kk) == 0;  // kk == 64: every lane
+        cmpx(v, k, j, lower != desc_block);
+      }
+    }
+    // ascending list (d, p) vs descending incoming: the pairwise minima are the 64 smallest of the union (bitonic)
+    {
+      const bool in_less = (v < d) || (v == d && k < p);
+      d = in_less ? v : d;
+      p = in_less ? k : p;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) cmpx(d, p, j, (lane & j) == 0);
+    thr = readlane_f(d, K - 1);
+    thrp = readlane_u(p, K - 1);
+  }
 };
 
 
