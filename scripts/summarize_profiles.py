@@ -16,9 +16,13 @@ kt = glob.glob(f"gpurun_out/prof_{tag}_kt/*/*_kernel_stats.csv")[0]
 shutil.copy(kt, f"profiles/{tag}_bench_kernel_stats.csv")
 
 
+# dominant kernel of the pipeline: the MFMA list ranking when the MFMA path ran, else the VALU list scan
+KERNEL = r"filter_kernel<\d+, \d+, false>|scan_kernel<\d+, 0, false, false>"
+
+
 def scan_avg(pattern, counter):
     f = glob.glob(pattern)[0]
-    rows = [r for r in csv.DictReader(open(f)) if re.search(r"scan_kernel<\d+, 0, false, false>", r["Kernel_Name"])
+    rows = [r for r in csv.DictReader(open(f)) if re.search(KERNEL, r["Kernel_Name"])
             and r["Counter_Name"] == counter]
     vals = [float(r["Counter_Value"]) for r in rows]
     vals = vals[-5:]  # the timed steps (same nprobe); earlier launches are warm-up / recall evaluation
@@ -28,7 +32,7 @@ def scan_avg(pattern, counter):
 fetch, n1, name = scan_avg(f"gpurun_out/prof_{tag}_fetch/*/*_counter_collection.csv", "FETCH_SIZE")
 write, n2, _ = scan_avg(f"gpurun_out/prof_{tag}_write/*/*_counter_collection.csv", "WRITE_SIZE")
 stats = {r["Name"]: r for r in csv.DictReader(open(kt))}
-scan = next(v for k, v in stats.items() if re.search(r"scan_kernel<\d+, 0, false, false>", k))
+scan = max((v for k, v in stats.items() if re.search(KERNEL, k)), key=lambda v: float(v["TotalDurationNs"]))
 out = {"workload": workload, "kernel": name, "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
        "hbm_bytes_per_launch": int((2.0 * fetch + write) * 1024),
        "avg_launch_ns_rocprof": float(scan["AverageNs"]), "calls": int(scan["Calls"]),

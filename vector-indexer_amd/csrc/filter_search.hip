@@ -198,7 +198,9 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
     pos = c_ ? tp_ : pos;     \
   }
 
-template <int NG, int NBUF>  // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0
+// NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0.  TABLE only names the instance
+// that ranks the centroid table (coarse step), so that profiles tell it from the list scan.
+template <int NG, int NBUF, bool TABLE>
 __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterArgs a) {
   constexpr int kTileFloats = 2 * NG * 256 + 64;
   __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
@@ -299,10 +301,10 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
           bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
           bm1 = fminf(bm1, p);
         }
-        if (qlive) a.brec[(size_t)bi + 2u * blk] = make_float4(bm1, bm2, bm3, bm4);
+        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + 2u * blk] = make_float4(bm1, bm2, bm3, bm4);
         // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
         const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
-        {
+        if (!(a.xmode & 16u)) {
           const uint32_t e = __float_as_uint(bm1) & 31u, r = e & 15u;
           float v = bm1;
           uint32_t pos = pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2);
@@ -777,8 +779,10 @@ template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, hipStream_t st) {
   if (nitems == 0) return VI_OK;
   static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
-  if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1>), dim3(nitems), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((filter_kernel<NG, 2>), dim3(nitems), dim3(256), 0, st, a);
+  const bool table = a.qoff == nullptr;
+  if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true>), dim3(nitems), dim3(256), 0, st, a);
+  else if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1, false>), dim3(nitems), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((filter_kernel<NG, 2, false>), dim3(nitems), dim3(256), 0, st, a);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
