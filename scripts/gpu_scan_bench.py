@@ -47,7 +47,5 @@ def run(label, n_probe, reps=6, **env):
 
 for p in (16,):
     run("filter default", p)
-    run("xmode 2 (no epilogue)", p, VI_FILTER_XMODE=2)
-    run("xmode 8 (no block-record store)", p, VI_FILTER_XMODE=8)
-    run("xmode 16 (no b1 insert)", p, VI_FILTER_XMODE=16)
-    run("xmode 24", p, VI_FILTER_XMODE=24)
+    run("stats: list select", p, VI_FILTER_STATS=1)
+    run("stats: coarse select", p, VI_FILTER_STATS=2)

@@ -58,12 +58,13 @@ struct SearchWorkspace {
   DevBuf<float> V;
   // generic (large k / n_probe) path
   // MFMA filter path (filter_search.hip)
-  DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list
+  DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list ...
+  uint64_t c_nq = 0;                        // ... for this batch size
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
-  DevBuf<uint32_t> pair_relb, qtotb, qoffb; // block-record offsets
+  DevBuf<uint32_t> tile_start, pair_pos;    // block records: first tile of each list; position of a pair in its list
   DevBuf<float> gval;                       // group records: 4 smallest values per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and their positions
-  DevBuf<float> brec;                       // block records: 4 smallest values per (query, probe, block, lane half)
+  DevBuf<float> brec;                       // block records: 4 smallest values per (tile, lane half, query of the group)
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

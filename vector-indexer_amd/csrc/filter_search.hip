@@ -89,53 +89,48 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
 // ------------------------------------------------------------------------------------------
 // record bookkeeping: where the records of (query, probe) start
 // ------------------------------------------------------------------------------------------
-// rel[q*P+r] = group records of the query's probes before rank r ; qtot[q] = group records of the query ;
-// relb / qtotb = the same for block records (2 per 64-vector block of a probed list)
+// rel[q*P+r] = group records of the query's probes before rank r ; qtot[q] = group records of the query
 __global__ void pair_groups_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nq, uint32_t P,
-                                   uint32_t segb0, uint32_t *rel, uint32_t *qtot, uint32_t *relb, uint32_t *qtotb) {
+                                   uint32_t segb0, uint32_t *rel, uint32_t *qtot) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
-  uint32_t run = 0, runb = 0;
+  uint32_t run = 0;
   for (uint32_t r = 0; r < P; ++r) {
     const uint32_t l = probes[(size_t)q * P + r];
     rel[(size_t)q * P + r] = run;
-    relb[(size_t)q * P + r] = runb;
     if (l != kNoPos) {
       uint32_t sb;
       run += 2u * list_segments(list_len[l], segb0, &sb);
-      runb += 2u * ((list_len[l] + 63u) / 64u);
     }
   }
   qtot[q] = run;
-  qtotb[q] = runb;
 }
 
-// qoff / qoffb = exclusive scans of qtot / qtotb over the queries (one workgroup), [nq] = totals
-__global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, const uint32_t *qtotb, uint32_t nq,
-                                                             uint32_t *qoff, uint32_t *qoffb) {
-  __shared__ uint32_t s[16], sb[16];
+// qoff = exclusive scan of qtot over the queries (one workgroup), qoff[nq] = total
+__global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
+  __shared__ uint32_t s[16];
   const uint32_t t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const uint32_t per = (nq + 1023) / 1024;
   const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
-  uint32_t sum = 0, sumb = 0;
-  for (uint32_t i = beg; i < end; ++i) { sum += qtot[i]; sumb += qtotb[i]; }
-  uint32_t inc = sum, incb = sumb;
+  uint32_t sum = 0;
+  for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
+  uint32_t inc = sum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t x = (uint32_t)__shfl_up((int)inc, o), y = (uint32_t)__shfl_up((int)incb, o);
-    if (lane >= o) { inc += x; incb += y; }
+    const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= o) inc += x;
   }
-  if (lane == 63) { s[wave] = inc; sb[wave] = incb; }
+  if (lane == 63) s[wave] = inc;
   __syncthreads();
-  uint32_t w = 0, wb = 0, tot = 0, totb = 0;
+  uint32_t w = 0, tot = 0;
   for (int i = 0; i < 16; ++i) {
-    if (i < wave) { w += s[i]; wb += sb[i]; }
-    tot += s[i]; totb += sb[i];
+    if (i < wave) w += s[i];
+    tot += s[i];
   }
-  uint32_t run = w + inc - sum, runb = wb + incb - sumb;
-  for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; qoffb[i] = runb; runb += qtotb[i]; }
-  if (t == 0) { qoff[nq] = tot; qoffb[nq] = totb; }
+  uint32_t run = w + inc - sum;
+  for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
+  if (t == 0) qoff[nq] = tot;
 }
 
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
@@ -153,9 +148,9 @@ struct FilterArgs {
   const float *Q;
   const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs;
   uint32_t nlists, P, segb0;
-  const uint32_t *qoff, *rel;    // group-record offsets (lists) ...
-  const uint32_t *qoffb, *relb;  // ... block-record offsets ...
-  uint32_t rec_stride, brec_stride;  // ... or fixed numbers of records per slot when qoff is null (coarse table)
+  const uint32_t *qoff, *rel;  // group-record offsets (lists) ...
+  uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
+  const uint32_t *tile_start;  // block records: first (128-query group, block) tile of each list
   float4 *gval;
   uint4 *gpos;
   float4 *brec;
@@ -245,8 +240,9 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
   uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos;  // (T3 only guards: its position is never needed)
-  uint32_t bi = 0;  // this lane's first block record (record counts are checked < 2^32 on the host)
-  if (qlive) bi = (a.qoffb ? a.qoffb[qid] + a.relb[slot] : slot * a.brec_stride) + (uint32_t)h;
+  // block records are item-major — [tile = (query group, block)][lane half][query of the group] — so that a
+  // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
+  const uint32_t bi = (a.tile_start[l] + chunk * nblk) * 256u + 128u * (uint32_t)h + jq_grp;
 
   tile_dma<NG>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
@@ -301,7 +297,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
           bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
           bm1 = fminf(bm1, p);
         }
-        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + 2u * blk] = make_float4(bm1, bm2, bm3, bm4);
+        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + 256u * blk] = make_float4(bm1, bm2, bm3, bm4);
         // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
         const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
         if (!(a.xmode & 16u)) {
@@ -352,7 +348,7 @@ struct SelectCommon {
 // the query's probes, one per lane r < P
 struct ProbeRegs {
   uint32_t rel, ng;   // first group record (relative to the query's) / number of group records of the probe
-  uint32_t boff;      // first block record of the probe (absolute)
+  uint32_t boff;      // block record of (block 0, lane half 0) of the probe; + 256 per block, + 128 for half 1
   uint32_t len, fb;   // list length and first block
   uint32_t segb;      // blocks per segment
   uint32_t g;         // candidate-order rank (shard visiting order)
@@ -379,6 +375,23 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
     sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
   }
   return acc;
+}
+
+// The select kernels are latency-sensitive code executed once per query; inlining the two heavy pieces at
+// every call site made them ~150 KB each and instruction-fetch bound.  They are real functions with their state
+// passed and returned in registers.
+__device__ __attribute__((noinline)) WaveTopK offer_bulk_fn(WaveTopK s, float dist, uint32_t pos, int K) {
+  s.offer_bulk(dist, pos, K);
+  return s;
+}
+
+// exact distance of (qrow, xv) on live lanes, then offer (distance, key) to `sel`
+__device__ __attribute__((noinline)) WaveTopK exact_batch_fn(WaveTopK sel, const float *qrow, const float4 *xv,
+                                                              uint32_t dim, bool live, uint32_t key, int K) {
+  float d = INFINITY;
+  if (live) d = exact_pair(qrow, xv, dim);
+  sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
 }
 
 // vector (within its 64-vector block) of element e of a lane-block: lane half hh owns rows (r&3)+8(r>>2)+4hh of
@@ -425,10 +438,9 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t g = (uint32_t)__shfl((int)pr.g, (int)r);
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     live = live && pos < len;
-    float d = INFINITY;
-    if (live) d = exact_pair(qrow, c.blocks + ((size_t)(fb + pos / kWave) * c.dq) * kWave + (pos % kWave), c.dim);
     n_exact += (uint32_t)__popcll(__ballot(live));
-    sel.offer_bulk(d, live ? ((g << kPosBits) | pos) : kNoPos, (int)K);
+    sel = exact_batch_fn(sel, qrow, c.blocks + ((size_t)(fb + (live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave),
+                         c.dim, live, (g << kPosBits) | pos, (int)K);
   };
   auto drain_pick = [&]() {
     while (npick > 0) {
@@ -468,12 +480,12 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       const uint32_t r = ck >> (kBlkBits + 1), blk = (ck >> 1) & ((1u << kBlkBits) - 1u), hh = ck & 1u;
       const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)r);
       float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-      if (live) B = c.brec[(size_t)boff + 2u * blk + hh];
+      if (live) B = c.brec[(size_t)boff + 256u * blk + 128u * hh];
       if (mode == 0) {
-        s1.offer_bulk(B.x, live ? 0u : kNoPos, (int)K);
-        s1.offer_bulk(B.y, live ? 1u : kNoPos, (int)K);
-        s1.offer_bulk(B.z, live ? 2u : kNoPos, (int)K);
-        s1.offer_bulk(B.w, live ? 3u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, B.x, live ? 0u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, B.y, live ? 1u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, B.z, live ? 2u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, B.w, live ? 3u : kNoPos, (int)K);
       } else {
         n_consult += cnt;
         const bool whole = live && B.w <= thr;  // rows missing from the record are only known to be >= b4
@@ -553,15 +565,15 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
       const bool live = gidx < G;
-      s1.offer_bulk(group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
     }
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
       const bool live = gidx < G;
       const float4 T = group_values(gidx, live);
-      s1.offer_bulk(T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
-      s1.offer_bulk(T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
-      s1.offer_bulk(T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
     }
     thr = threshold_of(readlane_f(s1.d, (int)K - 1));
     for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
@@ -658,7 +670,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
 struct SelectArgs {
   SelectCommon c;
   uint32_t nq, P, k, segb0;
-  const uint32_t *qoff, *qtot, *rel, *qoffb, *relb;
+  const uint32_t *qoff, *qtot, *rel, *pair_pos, *tile_start;
   const uint32_t *probes, *gorder, *first_block, *list_len;
   const uint64_t *ext_ids;
   float *D;
@@ -681,10 +693,11 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
     mylist = a.probes[s];
     pr.g = a.gorder[s];
     pr.rel = a.rel[s];
-    pr.boff = a.qoffb[q] + a.relb[s];
     if (mylist != kNoPos) {
       pr.len = a.list_len[mylist];
       pr.fb = a.first_block[mylist];
+      const uint32_t pp = a.pair_pos[s];  // where the pair sits among the pairs of its list
+      pr.boff = (a.tile_start[mylist] + (pp / kGroupQ) * ((pr.len + 63u) / 64u)) * 256u + (pp % kGroupQ);
       pr.ng = 2u * list_segments(pr.len, a.segb0, &pr.segb);
     }
   }
@@ -721,12 +734,12 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
 
 struct CoarseSelectArgs {
   SelectCommon c;  // blocks = centroid table
-  uint32_t nq, P, nlists, segb, recs, brecs;  // recs / brecs = group / block records per query
+  uint32_t nq, P, nlists, segb, recs;  // recs = group records per query
   const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt;
   // record counts of the list phase (what pair_groups_kernel computes otherwise)
   uint32_t list_segb0;
-  uint32_t *rel, *qtot, *relb, *qtotb;
+  uint32_t *rel, *qtot;
 };
 
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
@@ -738,7 +751,10 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
   ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, 0u};
-  if (lane == 0) { pr.ng = a.recs; pr.boff = q * a.brecs; pr.len = a.nlists; pr.segb = a.segb; }
+  if (lane == 0) {
+    pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb;
+    pr.boff = (q / kGroupQ) * ((a.nlists + 63u) / 64u) * 256u + (q % kGroupQ);  // pairs = iota: the query's own position
+  }
   WaveTopK sel;
   select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
               s_lcache[wave], sel);
@@ -750,29 +766,21 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
     a.gorder[(size_t)q * a.P + lane] = g;
     if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
   }
-  // records of the list phase: 2 per (probe, segment) and 2 per (probe, block); query_offsets_kernel turns the
-  // per-query totals into offsets
-  uint32_t ng = 0, nb = 0;
+  // group records of the list phase: 2 per (probe, segment); query_offsets_kernel turns the per-query totals
+  // into offsets
+  uint32_t ng = 0;
   if (mylist != kNoPos) {
-    const uint32_t len = a.list_len[mylist];
     uint32_t sb;
-    ng = 2u * list_segments(len, a.list_segb0, &sb);
-    nb = 2u * ((len + 63u) / 64u);
+    ng = 2u * list_segments(a.list_len[mylist], a.list_segb0, &sb);
   }
-  uint32_t ig = ng, ib = nb;
+  uint32_t ig = ng;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t x = (uint32_t)__shfl_up((int)ig, o), y = (uint32_t)__shfl_up((int)ib, o);
-    if (lane >= o) { ig += x; ib += y; }
+    const uint32_t x = (uint32_t)__shfl_up((int)ig, o);
+    if (lane >= o) ig += x;
   }
-  if ((uint32_t)lane < a.P) {
-    a.rel[(size_t)q * a.P + lane] = ig - ng;
-    a.relb[(size_t)q * a.P + lane] = ib - nb;
-  }
-  if (lane == 63) {
-    a.qtot[q] = ig;
-    a.qtotb[q] = ib;
-  }
+  if ((uint32_t)lane < a.P) a.rel[(size_t)q * a.P + lane] = ig - ng;
+  if (lane == 63) a.qtot[q] = ig;
 }
 
 template <int NG>
@@ -883,7 +891,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   const uint32_t segb0 = 4;
   uint32_t segb;
   const uint32_t nseg = list_segments((uint32_t)nlists, segb0, &segb);
-  const uint32_t recs = 2u * nseg, brecs = 2u * (uint32_t)ix.centroids.nblocks;
+  const uint32_t recs = 2u * nseg;
   const uint32_t ngroups = (uint32_t)((nq + kGroupQ - 1) / kGroupQ);
   const uint32_t h_seg[2] = {0u, (uint32_t)nq}, h_item[2] = {0u, ngroups * nseg};
   VI_TRY(ws.c_seg.reserve(2));
@@ -891,26 +899,31 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.c_pairs.reserve(nq));
   VI_TRY(ws.gval.reserve(nq * recs * 4));
   VI_TRY(ws.gpos.reserve(nq * recs * 4));
-  VI_TRY(ws.brec.reserve(nq * brecs * 4));
+  VI_TRY(ws.brec.reserve((uint64_t)ngroups * ix.centroids.nblocks * 256 * 4));
   VI_TRY(ws.stats.reserve(8));
-  VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
-  VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.c_pairs.p, (uint32_t)nq);
+  if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
+    VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
+    VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.c_pairs.p, (uint32_t)nq);
+    VI_HIP(hipGetLastError());
+    VI_HIP(hipStreamSynchronize(st));  // h_seg / h_item live on this stack frame
+    ws.c_nq = nq;
+  }
   {
     FilterArgs a{};
     a.blocks = (const float4 *)ix.centroids.blocks.p; a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
     a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
     a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
-    a.qoffb = nullptr; a.relb = nullptr; a.brec_stride = brecs;
+    a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, st));
   }
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
-                       (uint32_t)nlists, segb, recs, brecs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
-                       ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p};
-    a.c.dbg = nullptr;
+                       (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
+                       ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
+    { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
@@ -942,9 +955,6 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
-  VI_TRY(ws.pair_relb.reserve(nq * P));
-  VI_TRY(ws.qtotb.reserve(nq));
-  VI_TRY(ws.qoffb.reserve(nq + 1));
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
@@ -954,10 +964,9 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     } else {
       VI_TRY(stage_coarse(ix, Qd, nq, P, st));
       hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
-                         ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p, ws.pair_relb.p, ws.qtotb.p);
+                         ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p);
     }
-    hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, ws.qtotb.p, (uint32_t)nq, ws.qoff.p,
-                       ws.qoffb.p);
+    hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
@@ -967,7 +976,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];
-  const uint64_t nrec = hstats[4], nbrec = hstats[5];
+  const uint64_t nrec = hstats[4], nbrec = hstats[3] * 256;  // block records: 2 x 128 per (query group, block) tile
   if (nrec >= (1ull << 31) || nbrec >= (1ull << 32)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
   VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec) * 4));
@@ -980,7 +989,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
     a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
-    a.qoffb = ws.qoffb.p; a.relb = ws.pair_relb.p; a.brec_stride = 0;
+    a.tile_start = ws.tile_start.p;
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
     VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], st));
@@ -989,8 +998,9 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 4. select ----
   {
     SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2), (uint32_t)nq, P, (uint32_t)k, segb0,
-                 ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.qoffb.p, ws.pair_relb.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
+                 ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
+    { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
     hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }

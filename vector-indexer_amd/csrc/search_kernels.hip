@@ -379,15 +379,16 @@ __device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l) 
 __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
                                                           uint32_t nlists, uint32_t qg, uint32_t segb0,
                                                           uint32_t *seg_start, uint32_t *item_start,
-                                                          uint32_t *segrun_start, uint32_t *cursor, uint64_t *stats) {
-  __shared__ uint32_t s_seg[16], s_item[16], s_run[16];
+                                                          uint32_t *segrun_start, uint32_t *cursor, uint64_t *stats,
+                                                          uint32_t *tile_start) {
+  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
   const uint32_t t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   const uint4 *cnt4 = reinterpret_cast<const uint4 *>(cnt);  // kSubBins == 8: two uint4 per list
-  uint32_t seg = 0, item = 0, run = 0;
-  unsigned long long vec = 0, tb = 0, rec = 0, brc = 0;
+  uint32_t seg = 0, item = 0, run = 0, tile = 0;
+  unsigned long long vec = 0, rec = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
     const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
@@ -399,39 +400,34 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     item += chunks * ns;
     run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * len;
-    tb += (unsigned long long)chunks * ((len + 63) / 64);
+    tile += chunks * ((len + 63) / 64);  // (query group, block) tiles; < 2^24 enforced by the MFMA path's host code
     rec += 2ull * c * ns;
-    brc += 2ull * c * ((len + 63) / 64);
   }
   // inclusive scans across the wave, then across the 16 waves
-  uint32_t iseg = seg, iitem = item, irun = run;
+  uint32_t iseg = seg, iitem = item, irun = run, itile = tile;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t a = (uint32_t)__shfl_up((int)iseg, o), b = (uint32_t)__shfl_up((int)iitem, o);
-    const uint32_t r = (uint32_t)__shfl_up((int)irun, o);
-    if (lane >= o) { iseg += a; iitem += b; irun += r; }
+    const uint32_t r = (uint32_t)__shfl_up((int)irun, o), tt = (uint32_t)__shfl_up((int)itile, o);
+    if (lane >= o) { iseg += a; iitem += b; irun += r; itile += tt; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     vec += __shfl_xor(vec, o);
-    tb += __shfl_xor(tb, o);
     rec += __shfl_xor(rec, o);
-    brc += __shfl_xor(brc, o);
   }
-  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; }
+  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
   if (lane == 0) {
     atomicAdd((unsigned long long *)&stats[0], vec);  // scanned vectors
-    atomicAdd((unsigned long long *)&stats[3], tb);   // (query group, block) tiles
     atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
-    atomicAdd((unsigned long long *)&stats[5], brc);  // MFMA path: block records = 2 per (pair, block)
   }
   __syncthreads();
-  uint32_t wseg = 0, witem = 0, wrun = 0, tseg = 0, titem = 0, trun = 0;
+  uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
   for (int w = 0; w < 16; ++w) {
-    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; }
-    tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w];
+    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; wtile += s_tile[w]; }
+    tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
   }
-  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run;
+  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
   uint4 *cur4 = reinterpret_cast<uint4 *>(cursor);
   for (uint32_t l = beg; l < end; ++l) {
     const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
@@ -439,12 +435,14 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
+    if (tile_start) tile_start[l] = rt;
     // each sub-bin scatters into its own slice of the list's segment
     uint4 u0, u1;
     u0.x = rs; u0.y = u0.x + c0.x; u0.z = u0.y + c0.y; u0.w = u0.z + c0.z;
     u1.x = u0.w + c0.w; u1.y = u1.x + c1.x; u1.z = u1.y + c1.y; u1.w = u1.z + c1.z;
     cur4[2 * l] = u0; cur4[2 * l + 1] = u1;
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
+    rt += ((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
@@ -452,6 +450,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     segrun_start[nlists] = trun;
     stats[1] = titem;
     stats[2] = trun;
+    stats[3] = ttile;  // (query group, block) tiles
   }
 }
 
@@ -464,13 +463,14 @@ __global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_le
 }
 
 __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t P, uint32_t *cursor,
-                                     uint32_t *pairs, uint32_t total) {
+                                     uint32_t *pairs, uint32_t total, const uint32_t *seg_start, uint32_t *pair_pos) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint32_t l = probes[i];
   if (l == kNoPos || list_len[l] == 0) return;
   const uint32_t pos = atomicAdd(&cursor[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
   pairs[pos] = i;  // slot id = q*P + rank
+  if (pair_pos) pair_pos[i] = pos - seg_start[l];  // MFMA path: where the pair sits among the pairs of its list
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1019,7 +1019,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + nlists * kSubBins, ws.stats.p);
+                     ws.cnt.p + nlists * kSubBins, ws.stats.p, (uint32_t *)nullptr);
   VI_HIP(hipGetLastError());
   // exact work-item / segment-run counts size the scan grid and its scratch; the host waits for them while the
   // scatter runs
@@ -1029,7 +1029,8 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
-                       ix.list_len.p, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
+                       ix.list_len.p, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p,
+                       (uint32_t *)nullptr);
     VI_HIP(hipGetLastError());
   }
   VI_HIP(hipEventSynchronize(ix.ev[5]));
@@ -1175,6 +1176,8 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(total));
+  VI_TRY(ws.pair_pos.reserve(total));
+  VI_TRY(ws.tile_start.reserve(nlists + 1));
   VI_TRY(ws.stats.reserve(8));
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
@@ -1184,13 +1187,13 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   }
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + nlists * kSubBins, ws.stats.p);
+                     ws.cnt.p + nlists * kSubBins, ws.stats.p, ws.tile_start.p);
   VI_HIP(hipGetLastError());
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
-                     ws.cnt.p + nlists * kSubBins, ws.pairs.p, total);
+                     ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
   VI_HIP(hipGetLastError());
   VI_HIP(hipEventSynchronize(ix.ev[5]));
   return VI_OK;
