@@ -61,6 +61,7 @@ struct SearchWorkspace {
   DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list ...
   uint64_t c_nq = 0;                        // ... for this batch size
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
+  DevBuf<uint32_t> item_list;               // list of each rank work item
   DevBuf<uint32_t> tile_start, pair_pos;    // block records: first tile of each list; position of a pair in its list
   DevBuf<float> gval;                       // group records: 4 smallest values per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and their positions
@@ -82,7 +83,8 @@ struct DeviceIndex {
   DevBuf<uint32_t> list_len;          // [nlists]  (0 => not resident here / empty)
   DevBuf<uint32_t> list_shard;        // [nlists]
   DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
-  DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (+inf on pad slots)
+  DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (3e38 on pad slots)
+  DevBuf<uint32_t> lists_bf16, cent_bf16;  // bf16 hi/lo images of the blocks for the MFMA ranking (filter_search.hip)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   DevBuf<float> cent_xnorm;           // same for the coarse table
   float cent_xmax2 = 0.0f;

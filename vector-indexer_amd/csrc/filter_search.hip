@@ -87,6 +87,48 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 x 3 ranking: every stored value x is split as hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (|x - hi - lo| <= 2^-18 |x|); q.v ~ hi.hi + hi.lo + lo.hi on the bf16 matrix pipe (16x the f32 rate)
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rn(float x) {  // round-to-nearest-even, finite inputs
+  const uint32_t b = __float_as_uint(x);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+  const uint32_t h0 = bf16_rn(x0), h1 = bf16_rn(x1);
+  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);  // exact
+  hi = h0 | (h1 << 16);
+  lo = bf16_rn(r0) | (bf16_rn(r1) << 16);
+}
+__device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, float scale, uint4 &hi, uint4 &lo) {
+  split_pair(scale * lo4.x, scale * lo4.y, hi.x, lo.x);
+  split_pair(scale * lo4.z, scale * lo4.w, hi.y, lo.y);
+  split_pair(scale * hi4.x, scale * hi4.y, hi.z, lo.z);
+  split_pair(scale * hi4.z, scale * hi4.w, hi.w, lo.w);
+}
+
+// f32 blocks [quad][64] float4 -> bf16 blocks [chunk of 16 dims][plane hi/lo][half of 8 dims][64] x 16 B: the
+// image a 32x32x16 MFMA wants (lane (j,h) reads the 8 consecutive dims 16c+8h.. of vector j as one ds_read_b128),
+// same bytes per block as the f32 form
+__global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, uint4 *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block, chunk, half, vector)
+  const uint32_t nc = dq / 4;
+  if (t >= nblocks * nc * 2 * 64) return;
+  const uint32_t v = (uint32_t)(t & 63), h = (uint32_t)((t >> 6) & 1);
+  const uint64_t bc = t >> 7;
+  const uint32_t c = (uint32_t)(bc % nc);
+  const uint64_t b = bc / nc;
+  const float4 *src = blocks + (b * dq + 4 * c + 2 * h) * 64 + v;
+  uint4 hi, lo;
+  split8(src[0], src[64], 1.0f, hi, lo);
+  uint4 *dst = out + ((b * nc + c) * 4) * 64;
+  dst[(0 * 2 + h) * 64 + v] = hi;
+  dst[(1 * 2 + h) * 64 + v] = lo;
+}
+
+// ------------------------------------------------------------------------------------------
 // record bookkeeping: where the records of (query, probe) start
 // ------------------------------------------------------------------------------------------
 // rel[q*P+r] = group records of the query's probes before rank r ; qtot[q] = group records of the query
@@ -133,6 +175,18 @@ __global__ void __launch_bounds__(1024) query_offsets_kernel(const uint32_t *qto
   if (t == 0) qoff[nq] = tot;
 }
 
+// list of every work item: keeps a 12-step dependent binary search out of each rank workgroup's prologue
+__global__ void item_list_kernel(const uint32_t *item_start, uint32_t nlists, uint32_t nitems, uint32_t *item_list) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= nitems) return;
+  uint32_t lo = 0, hi = nlists;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (item_start[mid] <= item) lo = mid; else hi = mid;
+  }
+  item_list[item] = lo;
+}
+
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -142,7 +196,7 @@ __global__ void iota_kernel(uint32_t *p, uint32_t n) {
 // rank kernel
 // ------------------------------------------------------------------------------------------
 struct FilterArgs {
-  const float4 *blocks;
+  const float4 *blocks;  // f32 blocks, or the bf16 hi/lo image of the same size (BF16 kernels)
   const float *xnorm;
   uint32_t dq, dim;
   const float *Q;
@@ -151,6 +205,7 @@ struct FilterArgs {
   const uint32_t *qoff, *rel;  // group-record offsets (lists) ...
   uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
   const uint32_t *tile_start;  // block records: first (128-query group, block) tile of each list
+  const uint32_t *item_list;   // list of each work item (null: binary search over item_start)
   float4 *gval;
   uint4 *gpos;
   float4 *brec;
@@ -195,17 +250,23 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
 
 // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0.  TABLE only names the instance
 // that ranks the centroid table (coarse step), so that profiles tell it from the list scan.
-template <int NG, int NBUF, bool TABLE>
+// BF16: rank with three bf16 MFMAs per 16 dims (hi.hi + hi.lo + lo.hi) instead of eight f32 MFMAs.
+template <int NG, int NBUF, bool TABLE, bool BF16>
 __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterArgs a) {
   constexpr int kTileFloats = 2 * NG * 256 + 64;
   __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const uint32_t item = blockIdx.x;  // grid == number of items
-  uint32_t lo = 0, hi = a.nlists;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a.item_start[mid] <= item) lo = mid; else hi = mid;
+  uint32_t lo = 0;
+  if (a.item_list) {
+    lo = a.item_list[item];
+  } else {
+    uint32_t hi = a.nlists;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.item_start[mid] <= item) lo = mid; else hi = mid;
+    }
   }
   const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
   const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
@@ -229,13 +290,27 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   const uint32_t slot = qlive ? a.pairs[s0 + j0 + jq_grp] : 0u;
   const uint32_t qid = slot / a.P;
   const float *qrow = a.Q + (size_t)qid * a.dim;
-  float4 qf[NG];
+  float4 qf[NG];  // f32: -2q, dims 8g+4h.. ; BF16: qf[2c] = hi, qf[2c+1] = lo halves (bit patterns) of -2q, dims 16c+8h..
+  if constexpr (!BF16) {
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const uint32_t e = 8 * g + 4 * h;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qlive && e < a.dim) v = *reinterpret_cast<const float4 *>(qrow + e);
-    qf[g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+    for (int g = 0; g < NG; ++g) {
+      const uint32_t e = 8 * g + 4 * h;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qlive && e < a.dim) v = *reinterpret_cast<const float4 *>(qrow + e);
+      qf[g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NG / 2; ++c) {
+      const uint32_t e = 16 * c + 8 * h;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (qlive && e < a.dim) v0 = *reinterpret_cast<const float4 *>(qrow + e);
+      if (qlive && e + 4 < a.dim) v1 = *reinterpret_cast<const float4 *>(qrow + e + 4);
+      uint4 hi, lo;
+      split8(v0, v1, -2.0f, hi, lo);
+      qf[2 * c] = __builtin_bit_cast(float4, hi);
+      qf[2 * c + 1] = __builtin_bit_cast(float4, lo);
+    }
   }
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
@@ -265,18 +340,56 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
         acc0[4 * q4 + 0] = n0.x; acc0[4 * q4 + 1] = n0.y; acc0[4 * q4 + 2] = n0.z; acc0[4 * q4 + 3] = n0.w;
         acc1[4 * q4 + 0] = n1.x; acc1[4 * q4 + 1] = n1.y; acc1[4 * q4 + 2] = n1.z; acc1[4 * q4 + 3] = n1.w;
       }
+      if constexpr (!BF16) {
+        // A fragments are read one K group ahead of the MFMAs that consume them (the compiler would otherwise
+        // issue each pair of ds_read_b128 right before its 8 MFMAs and stall on the LDS latency every time)
+        float4 a0 = *reinterpret_cast<const float4 *>(s_tile + h * 256 + 4 * j);
+        float4 a1 = *reinterpret_cast<const float4 *>(s_tile + h * 256 + 4 * (32 + j));
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(s_tile + (2 * g + h) * 256 + 4 * j);
-        const float4 a1 = *reinterpret_cast<const float4 *>(s_tile + (2 * g + h) * 256 + 4 * (32 + j));
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qf[g].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qf[g].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qf[g].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, qf[g].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, qf[g].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qf[g].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qf[g].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+          float4 n0 = a0, n1 = a1;
+          if (g + 1 < NG) {
+            n0 = *reinterpret_cast<const float4 *>(s_tile + (2 * (g + 1) + h) * 256 + 4 * j);
+            n1 = *reinterpret_cast<const float4 *>(s_tile + (2 * (g + 1) + h) * 256 + 4 * (32 + j));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qf[g].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qf[g].x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qf[g].y, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, qf[g].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, qf[g].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qf[g].z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qf[g].w, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qf[g].w, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a0 = n0;
+          a1 = n1;
+        }
+      } else {
+        // image: [chunk][plane][half][vector] x 16 B; fragment (plane p, tile t) of chunk c for lane (j,h) =
+        // float4 index ((c*2 + p)*2 + h)*64 + 32t + j
+        auto frag = [&](int c, int p, int t) {
+          return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(s_tile + (((c * 2 + p) * 2 + h) * 64 + 32 * t + j) * 4));
+        };
+        // hi fragments of chunk c+1 are requested while the lo MFMAs of chunk c run, lo fragments of chunk c while
+        // its hi MFMAs run: 16 fragment registers, every read has MFMAs to hide behind
+        bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
+#pragma unroll
+        for (int c = 0; c < NG / 2; ++c) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
+          const bf16x8 l0 = frag(c, 1, 0), l1 = frag(c, 1, 1);
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c + 1 < NG / 2) { h0 = frag(c + 1, 0, 0); h1 = frag(c + 1, 0, 1); }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (!(a.xmode & 2u)) {
         // the four smallest of this lane's 32 values, element index in the low bits
@@ -784,29 +897,42 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
 }
 
 template <int NG>
-vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, hipStream_t st) {
+vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, bool bf16, hipStream_t st) {
   if (nitems == 0) return VI_OK;
   static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
   const bool table = a.qoff == nullptr;
-  if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true>), dim3(nitems), dim3(256), 0, st, a);
-  else if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1, false>), dim3(nitems), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((filter_kernel<NG, 2, false>), dim3(nitems), dim3(256), 0, st, a);
+  if (bf16) {
+    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, true>), dim3(nitems), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, true>), dim3(nitems), dim3(256), 0, st, a);
+  } else if (table) {
+    hipLaunchKernelGGL((filter_kernel<NG, 1, true, false>), dim3(nitems), dim3(256), 0, st, a);
+  } else if (nbuf == 1) {
+    hipLaunchKernelGGL((filter_kernel<NG, 1, false, false>), dim3(nitems), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((filter_kernel<NG, 2, false, false>), dim3(nitems), dim3(256), 0, st, a);
+  }
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
 
-vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, hipStream_t st) {
+vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, bool bf16, hipStream_t st) {
   switch (dq / 2) {  // dq is a multiple of 4
-    case 2: return launch_filter_t<2>(a, nitems, st);
-    case 4: return launch_filter_t<4>(a, nitems, st);
-    case 6: return launch_filter_t<6>(a, nitems, st);
-    case 8: return launch_filter_t<8>(a, nitems, st);
-    case 10: return launch_filter_t<10>(a, nitems, st);
-    case 12: return launch_filter_t<12>(a, nitems, st);
-    case 14: return launch_filter_t<14>(a, nitems, st);
-    case 16: return launch_filter_t<16>(a, nitems, st);
+    case 2: return launch_filter_t<2>(a, nitems, bf16, st);
+    case 4: return launch_filter_t<4>(a, nitems, bf16, st);
+    case 6: return launch_filter_t<6>(a, nitems, bf16, st);
+    case 8: return launch_filter_t<8>(a, nitems, bf16, st);
+    case 10: return launch_filter_t<10>(a, nitems, bf16, st);
+    case 12: return launch_filter_t<12>(a, nitems, bf16, st);
+    case 14: return launch_filter_t<14>(a, nitems, bf16, st);
+    case 16: return launch_filter_t<16>(a, nitems, bf16, st);
     default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
   }
+}
+
+// rank arithmetic: bf16 x 3 unless VI_FILTER_BF16=0 (f32 MFMA)
+bool rank_bf16() {
+  static const bool on = [] { const char *e = getenv("VI_FILTER_BF16"); return !(e && *e == '0'); }();
+  return on;
 }
 
 SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2) {
@@ -816,7 +942,13 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.gval = (const float4 *)ix.ws.gval.p; c.gpos = (const uint4 *)ix.ws.gpos.p;
   c.brec = (const float4 *)ix.ws.brec.p;
   c.gamma = (float)((ix.dim + 2.0) * u);
-  c.e_scale = (float)((ix.dim + 2.0) * u + 1.01 * std::ldexp(1.0, -18));
+  // |ranked value - (||v||^2 - 2 q.v)| <= e_scale (||q||^2 + 2 max||v||^2):
+  //   f32 MFMA : (D+2) u'  accumulation of D products + the norm
+  //   bf16 x 3 : 3 * 2^-18 for the dropped lo.lo product and the two split residuals, and (3D+2) * 2u' for the f32
+  //              accumulation of 3D exact bf16 products (2u': also covers an accumulator that truncates)
+  //   + 2^-18 for the 5 mantissa bits the rank kernel reuses as an index
+  const double acc = rank_bf16() ? (3.0 * ix.dim + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (ix.dim + 2.0) * u;
+  c.e_scale = (float)(acc + 1.01 * std::ldexp(1.0, -18));
   c.xmax2 = xmax2;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
@@ -868,6 +1000,21 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   VI_HIP(hipStreamSynchronize(ix->stream));
   std::memcpy(&f, &bits, 4);
   ix->cent_xmax2 = f;
+  // bf16 hi/lo images of the lists and of the centroid table (same size as the f32 blocks)
+  if ((ix->dim & 3) == 0 && ix->dim <= 128) {
+    const uint64_t per_block = (uint64_t)ix->dq * kWave * 4;  // uint32 words per block
+    VI_TRY(ix->lists_bf16.reserve(std::max<uint64_t>(1, ix->lists.nblocks * per_block)));
+    VI_TRY(ix->cent_bf16.reserve(std::max<uint64_t>(1, ix->centroids.nblocks * per_block)));
+    const uint64_t nt_l = ix->lists.nblocks * (ix->dq / 4) * 128, nt_c = ix->centroids.nblocks * (ix->dq / 4) * 128;
+    if (nt_l)
+      hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nt_l + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->lists.blocks.p, ix->dq, ix->lists.nblocks, (uint4 *)ix->lists_bf16.p);
+    if (nt_c)
+      hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nt_c + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->centroids.blocks.p, ix->dq, ix->centroids.nblocks, (uint4 *)ix->cent_bf16.p);
+    VI_HIP(hipGetLastError());
+    VI_HIP(hipStreamSynchronize(ix->stream));
+  }
   const uint32_t one_first[1] = {0u}, one_len[1] = {(uint32_t)ix->nlists};
   VI_TRY(ix->c_first.reserve(1));
   VI_TRY(ix->c_len.reserve(1));
@@ -911,13 +1058,14 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   }
   {
     FilterArgs a{};
-    a.blocks = (const float4 *)ix.centroids.blocks.p; a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
+    a.blocks = rank_bf16() ? (const float4 *)ix.cent_bf16.p : (const float4 *)ix.centroids.blocks.p;
+    a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
     a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
     a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
-    VI_TRY(launch_filter(a, dq, ngroups * nseg, st));
+    VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16(), st));
   }
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
@@ -985,14 +1133,23 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 3. rank on the matrix cores ----
   {
     FilterArgs a{};
-    a.blocks = (const float4 *)ix.lists.blocks.p; a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
+    a.blocks = rank_bf16() ? (const float4 *)ix.lists_bf16.p : (const float4 *)ix.lists.blocks.p;
+    a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
     a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
     a.tile_start = ws.tile_start.p;
+    const uint32_t nitems = (uint32_t)hstats[1];
+    VI_TRY(ws.item_list.reserve(std::max<uint32_t>(1, nitems)));
+    if (nitems) {
+      hipLaunchKernelGGL(item_list_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, ws.item_start.p,
+                         (uint32_t)nlists, nitems, ws.item_list.p);
+      VI_HIP(hipGetLastError());
+    }
+    a.item_list = ws.item_list.p;
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
-    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], st));
+    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_bf16(), st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----
