@@ -47,6 +47,5 @@ def run(label, n_probe, reps=6, **env):
 
 for p in (16,):
     run("default", p)
-    run("xmode 2 (no epilogue)", p, VI_FILTER_XMODE=2)
-    run("segb 8", p, VI_FILTER_SEGB=8)
-    run("segb 32", p, VI_FILTER_SEGB=32)
+    run("stats: list select", p, VI_FILTER_STATS=1)
+    run("stats: coarse select", p, VI_FILTER_STATS=2)

@@ -1099,10 +1099,12 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   const uint64_t nlists = ix.nlists;
   (void)K;
   const char *sb = getenv("VI_FILTER_SEGB");
-  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 16u;  // <= 1024 vectors per work item
+  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 32u;  // <= 2048 vectors per work item
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
+  VI_TRY(ws.stats.reserve(8));
+  if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 2 * sizeof(uint64_t), st));
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {

@@ -1016,7 +1016,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(nq * P));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
-  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6], [7] belong to the MFMA path's select
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
                      ws.cnt.p + nlists * kSubBins, ws.stats.p, (uint32_t *)nullptr);
@@ -1179,7 +1179,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pair_pos.reserve(total));
   VI_TRY(ws.tile_start.reserve(nlists + 1));
   VI_TRY(ws.stats.reserve(8));
-  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 8 * sizeof(uint64_t), st));
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6], [7] belong to the MFMA path's select
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total, P,
