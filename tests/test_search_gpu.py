@@ -204,7 +204,8 @@ def test_generic_path_equals_fast_path(tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("n,d,nlist,kind", [(20000, 64, 0, "gauss"), (6000, 128, 24, "gauss"), (4000, 96, 0, "gauss"),
                                             (5000, 32, 12, "clustered"), (3000, 8, 40, "grid"), (9000, 100, 30, "sift"),
-                                            (40000, 32, 1024, "gauss")])
+                                            (40000, 32, 1024, "gauss"), (4000, 32, 10, "offset"),
+                                            (5000, 128, 20, "wide")])
 def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
     """VI_FILTER=1 forces the f32-MFMA rank + exact re-evaluation pipeline (filter_search.hip).  Its result must
     be the oracle's, bit for bit, including ties, lists shorter than k and masses of duplicates (whole-group
@@ -215,13 +216,18 @@ def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
     elif kind == "clustered":
         centers = rng.standard_normal((8, d)).astype(np.float32) * 5
         X = (centers[rng.integers(0, 8, n)] + 0.2 * rng.standard_normal((n, d))).astype(np.float32)
+    elif kind == "offset":                                            # ||v||^2 - 2 q.v cancels catastrophically: the
+        X = (1000.0 + rng.standard_normal((n, d))).astype(np.float32)  # rank values say nothing, everything is re-evaluated
+    elif kind == "wide":                                              # 12 decades of dynamic range inside one vector
+        X = (rng.standard_normal((n, d)) * np.exp(rng.uniform(-14, 14, size=(n, d)))).astype(np.float32)
     elif kind == "grid":
         X = rng.integers(-2, 3, size=(n, d)).astype(np.float32)      # masses of exact ties / duplicates
     else:
         X = np.clip(np.round(np.abs(rng.standard_normal((n, d)) * 40 + 20)), 0, 218).astype(np.float32)
     orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
-    Q = np.concatenate([X[:100], (X[100:400] + 0.01 * rng.standard_normal((300, d))).astype(np.float32),
-                        rng.standard_normal((100, d)).astype(np.float32) * float(np.abs(X).mean() + 1)])
+    huge = np.stack([np.full(d, 3e15, np.float32), np.full(d, 1e20, np.float32)])  # ||q||^2 = 1e33 / inf: the rank
+    Q = np.concatenate([X[:100], (X[100:400] + 0.01 * rng.standard_normal((300, d))).astype(np.float32),  # values overflow
+                        rng.standard_normal((100, d)).astype(np.float32) * float(np.abs(X).mean() + 1), huge])
     monkeypatch.setenv("VI_FILTER", "1")
     for k, n_probe in [(10, 8), (1, 1), (64, 16), (10, 64), (5, 3)]:
         check_parity(orc, gpu, Q, k, n_probe)

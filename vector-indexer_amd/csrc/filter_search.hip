@@ -535,8 +535,11 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
   const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  // a query so large that the rank arithmetic may have overflowed (inf - inf = NaN, and NaN fails every guard
+  // below): trust no rank value, re-evaluate everything the query probes
+  const bool distrust = !(qn < 1.0e30f);
   auto threshold_of = [&](float mk) {  // (*) ; anything non-finite or huge means "no bound"
-    if (!(mk < 1.0e37f)) return INFINITY;
+    if (distrust || !(mk < 1.0e37f)) return INFINITY;
     const float scale = fmaxf(mk + qn, 0.0f) + E;
     return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
   };
@@ -601,7 +604,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
         s1 = offer_bulk_fn(s1, B.w, live ? 3u : kNoPos, (int)K);
       } else {
         n_consult += cnt;
-        const bool whole = live && B.w <= thr;  // rows missing from the record are only known to be >= b4
+        const bool whole = live && (B.w <= thr || distrust);  // rows missing from the record are only known to be >= b4
         const float bv[3] = {B.x, B.y, B.z};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -692,7 +695,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
       const uint32_t gidx = gb + lane;
       const float4 T = group_values(gidx, gidx < G);
-      any_full = any_full || __ballot(gidx < G && T.w <= thr) != 0ull;
+      any_full = any_full || __ballot(gidx < G && T.w <= thr) != 0ull;  // (distrust: thr = inf, stage 1b is moot)
     }
   }
   // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed values and leave the bound
@@ -744,7 +747,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     group_place(gidx, live, r, seg, hh);
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     const float4 T = group_values(gidx, live);
-    const bool full = live && T.w <= thr;
+    const bool full = live && (T.w <= thr || distrust);
     // positions are only needed by chunks that list something at or below thr
     uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
     if (live && !full && T.x <= thr) Pp = c.gpos[gbase + gidx];
