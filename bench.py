@@ -49,6 +49,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3  # dense f32 matrix peak: 256 CUs x 256 flop/clk x 2.4 GHz
+MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 matrix peak: 256 CUs x 4096 flop/clk x 2.4 GHz
 
 
 def make_dataset(n, d, nq, seed, device):
@@ -219,18 +220,27 @@ def main():
     common = {"algorithmic_bytes_per_launch": int(algo_bytes_rank), "avg_launch_ms": round(scan_s * 1000, 4),
               "coarse_ms": round(float(np.mean(coarse_ms)), 4), "pipeline_ms": round(float(np.mean(tot_ms)), 4)}
     if st["filter_tile_blocks"] > 0:
-        # MFMA path: the list scan is a dense f32 contraction (queries x list vectors x dims) on the matrix cores.
-        # Algorithmic flops = 2*D per (query, scanned vector) pair — the multiply-add of the norm-expanded distance;
-        # SURVEY §8d's 3*D counts the reference's (sub, mul, add), which this form does not execute.
+        # MFMA path.  The list scan is a dense contraction (queries x list vectors x dims) ranked on the bf16 matrix
+        # pipe with the operands split hi+lo: 3 bf16 products per element pair (hi.hi, hi.lo, lo.hi).  Algorithmic
+        # flops = 2*D per (query, scanned vector) pair (multiply-add of the norm-expanded distance; SURVEY 8d's 3*D
+        # counts the reference's sub/mul/add, which this form does not execute).  Peak = bf16 dense peak / 3.
+        tiles = st["filter_tile_blocks"]
+        dq = 4 * ((args.d + 15) // 16)
+        tile_bytes = tiles * (64 * dq * 16 + 256 * 16)  # one block image per 128-query group + its block records
         flops = 2.0 * args.d * st["scanned_vectors"]
         tf = flops / scan_s / 1e12 if scan_s > 0 else 0.0
-        roofline = {"kernel": "filter_kernel<NG,1,false> (f32-MFMA ranking of query-group x list-segment tiles)",
-                    "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None, "flops_per_launch": flops,
-                    "algorithmic_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common,
-                    "note": "one list block staged in LDS serves up to 128 queries, so the algorithmic byte rate "
-                            "(4*D+8 B per (query, scanned vector)) is far above what crosses HBM: the kernel is bound "
-                            "by the f32 matrix pipe, not by HBM"}
+        peak = MFMA_BF16_PEAK_TF / 3.0
+        roofline = {"kernel": "filter_kernel<NG,1,false,true> (bf16x3 MFMA ranking of query-group x list-segment tiles)",
+                    "bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "traffic": None, "flops_per_launch": flops,
+                    "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply",
+                    "tiles_per_launch": int(tiles), "tile_bytes_per_launch": int(tile_bytes),
+                    "tile_stream_GBps": round(tile_bytes / scan_s / 1e9, 1) if scan_s > 0 else 0.0,
+                    "survey_accounting_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common,
+                    "note": "a staged 64-vector block serves up to 128 queries, so SURVEY 8d's no-reuse accounting "
+                            "(4*D+8 B per (query, scanned vector) = survey_accounting_GBps) is far above HBM; "
+                            "tile_stream_GBps is what the kernel's tiles pull through L2 (block image per query group "
+                            "+ block records), traffic is what PMC saw cross to HBM/MALL per launch"}
     else:
         roofline = {"kernel": "scan_kernel<LISTS> (inverted-list L2 scan + wave top-k)", "bound": "hbm",
                     "achieved": round(algo_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
