@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "assign_mfma.hpp"
+#include "mfma_bf16.hpp"
 
 namespace vi {
 namespace {
@@ -61,6 +62,7 @@ struct MfmaArgs {
   uint32_t k;
   float margin_scale_x, margin_const;  // margin_i = margin_scale_x * ||x_i||^2 + margin_const
   uint32_t *label, *amb_list, *namb;
+  const float4 *img;  // bf16 kernels: hi/lo images of the centroid tiles (mfma_bf16.hpp)
 };
 
 // C tile staging, split in two halves (issue-early / write-late): the global loads of tile t+1 are
@@ -213,6 +215,146 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_kernel(MfmaArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 x 3 variant: the same sweep on the bf16 matrix pipe (16x the f32 rate, 3 products per multiply)
+// ------------------------------------------------------------------------------------------
+// centroid rows (row-major k x d) -> per 64-centroid tile the A-operand image of mfma_bf16.hpp
+__global__ void centroid_image_kernel(const float *C, uint32_t k, uint32_t d, uint32_t nc, uint4 *img) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, chunk, half, vector)
+  const uint64_t ntiles = (k + 63) / 64;
+  if (t >= ntiles * nc * 128) return;
+  const uint32_t v = (uint32_t)(t & 63), h = (uint32_t)((t >> 6) & 1);
+  const uint64_t bc = t >> 7;
+  const uint32_t c = (uint32_t)(bc % nc);
+  const uint64_t b = bc / nc;
+  const uint64_t row = b * 64 + v;
+  const uint32_t e = 16 * c + 8 * h;
+  float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+  if (row < k && e < d) x0 = *reinterpret_cast<const float4 *>(C + row * d + e);
+  if (row < k && e + 4 < d) x1 = *reinterpret_cast<const float4 *>(C + row * d + e + 4);
+  uint4 hi, lo;
+  split8(x0, x1, 1.0f, hi, lo);
+  uint4 *dst = img + ((b * nc + c) * 4) * 64;
+  dst[(0 * 2 + h) * 64 + v] = hi;
+  dst[(1 * 2 + h) * 64 + v] = lo;
+}
+
+__global__ void centroid_norm_pad_kernel(const float *cn, uint32_t k, uint32_t kpad, float *out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < kpad) out[c] = c < k ? cn[c] : INFINITY;  // pad rows never win
+}
+
+template <int NG>  // dims padded to 8*NG (NG even <= 16); 32 points per wave, 128 per workgroup
+__global__ void __launch_bounds__(256, 2) mfma_assign_bf16_kernel(MfmaArgs a) {
+  extern __shared__ float lds[];
+  constexpr int kImgFloats = 2 * NG * 256 + 64;  // image + 64 norms
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t pt = blockIdx.x * 128 + wave * 32 + j;
+  const bool live = pt < a.n;
+  const float *row = a.X + (size_t)(live ? pt : 0) * a.dim;
+  // B fragments: this lane's point, dims 16c+8h.., scaled by -2 (exact), split hi/lo: xf[2c] = hi, xf[2c+1] = lo
+  float4 xf[NG];
+  float xnv = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NG / 2; ++c) {
+    const uint32_t e = 16 * c + 8 * h;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (live && e < a.dim) v0 = *reinterpret_cast<const float4 *>(row + e);
+    if (live && e + 4 < a.dim) v1 = *reinterpret_cast<const float4 *>(row + e + 4);
+    xnv += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    uint4 hi, lo;
+    split8(v0, v1, -2.0f, hi, lo);
+    xf[2 * c] = __builtin_bit_cast(float4, hi);
+    xf[2 * c + 1] = __builtin_bit_cast(float4, lo);
+  }
+  float b1 = INFINITY, b2 = INFINITY;
+  uint32_t code = 0u;
+
+  const uint32_t ntiles = (a.k + kTileC - 1) / kTileC;
+  const size_t img_stride = (size_t)2 * NG * 64;  // float4 per tile image
+  tile_dma_image<NG>(lds, a.img, a.cn, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (uint32_t ct = 0; ct < ntiles; ++ct) {
+    const float *cur = lds + (ct & 1) * kImgFloats;
+    // next tile lands in the other buffer during this tile's MFMAs (everyone left it at the last barrier)
+    if (ct + 1 < ntiles)
+      tile_dma_image<NG>(lds + ((ct + 1) & 1) * kImgFloats, a.img + (ct + 1) * img_stride, a.cn + (size_t)(ct + 1) * kTileC,
+                         wave, lane);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // rows 8q + 4h + (0..3) live in regs 4q .. 4q+3
+      const float4 n0 = *reinterpret_cast<const float4 *>(cur + 2 * NG * 256 + 8 * q + 4 * h);
+      const float4 n1 = *reinterpret_cast<const float4 *>(cur + 2 * NG * 256 + 32 + 8 * q + 4 * h);
+      acc0[4 * q + 0] = n0.x; acc0[4 * q + 1] = n0.y; acc0[4 * q + 2] = n0.z; acc0[4 * q + 3] = n0.w;
+      acc1[4 * q + 0] = n1.x; acc1[4 * q + 1] = n1.y; acc1[4 * q + 2] = n1.z; acc1[4 * q + 3] = n1.w;
+    }
+    auto frag = [&](int c, int p, int t) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(cur + (((c * 2 + p) * 2 + h) * 64 + 32 * t + j) * 4));
+    };
+    bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
+#pragma unroll
+    for (int c = 0; c < NG / 2; ++c) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, xf[2 * c]), bl = __builtin_bit_cast(bf16x8, xf[2 * c + 1]);
+      const bf16x8 l0 = frag(c, 1, 0), l1 = frag(c, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NG / 2) { h0 = frag(c + 1, 0, 0); h1 = frag(c + 1, 0, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane-local running best / second best / code (code = tile*32 + rt*16 + reg)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc0[r];
+      code = v < b1 ? ct * 32 + r : code;
+      b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+      b1 = fminf(b1, v);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc1[r];
+      code = v < b1 ? ct * 32 + 16 + r : code;
+      b2 = __builtin_amdgcn_fmed3f(b1, b2, v);
+      b1 = fminf(b1, v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // next tile visible; this one free to be overwritten
+  }
+  // ---- merge the two lane halves (same point, disjoint centroid rows) ----
+  const uint32_t r = code & 15, rt = (code >> 4) & 1, ctb = code >> 5;
+  uint32_t cen = ctb * kTileC + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+  const float ob1 = __shfl_xor(b1, 32), ob2 = __shfl_xor(b2, 32);
+  const uint32_t ocen = (uint32_t)__shfl_xor((int)cen, 32);
+  const float xnt = xnv + __shfl_xor(xnv, 32);
+  const float nb1 = fminf(b1, ob1);
+  const float nb2 = fminf(fmaxf(b1, ob1), fminf(b2, ob2));
+  if (ob1 < b1 || (ob1 == b1 && ocen < cen)) cen = ocen;
+  if (h == 0 && live) {
+    const float margin = a.margin_scale_x * xnt + a.margin_const;
+    const bool sure = (nb2 - nb1) > margin;  // false for NaN / inf-inf
+    a.label[pt] = cen < a.k ? cen : 0u;
+    if (!sure) a.amb_list[atomicAdd(a.namb, 1u)] = pt;
+  }
+}
+
+template <int NG>
+vi_status launch_mfma_bf16(const MfmaArgs &a, hipStream_t st) {
+  const size_t smem = 2 * (2 * NG * 256 + 64) * sizeof(float);
+  VI_HIP(hipFuncSetAttribute((const void *)mfma_assign_bf16_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)smem));
+  hipLaunchKernelGGL((mfma_assign_bf16_kernel<NG>), dim3((a.n + 127) / 128), dim3(256), smem, st, a);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
 template <int NG, int NP>
 vi_status launch_mfma(const MfmaArgs &a, hipStream_t st) {
   const size_t smem = 2 * kTileFloats * sizeof(float);
@@ -243,15 +385,33 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   VI_HIP(hipStreamSynchronize(st));
   double cmax = 0.0;
   for (uint64_t c = 0; c < k; ++c) cmax = std::max(cmax, (double)h_cn[c]);
-  // margin_i = 2 (E_i + G_i), see the file header; computed in double, rounded up
+  // margin_i = 2 (E_i + G_i), see the file header; computed in double, rounded up.  bf16 x 3: E grows to
+  // (3D+2) 2u' (accumulating 3D exact bf16 products; 2u' also covers a truncating accumulator) + 3 * 2^-18
+  // (the dropped lo.lo product and the two split residuals)
+  static const bool bf16 = [] { const char *e = getenv("VI_ASSIGN_BF16"); return !(e && *e == '0'); }();
   const double u = 1.01 * std::ldexp(1.0, -24);
-  const double e = (d + 2.0) * u, g = (d / 8.0 + 8.0) * u * 2.0;
+  const double e = bf16 ? (3.0 * d + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (d + 2.0) * u;
+  const double g = (d / 8.0 + 8.0) * u * 2.0;
   MfmaArgs a{};
   a.X = Xd; a.dim = d; a.C = Cd; a.cn = ws.cn.p; a.k = (uint32_t)k;
   a.margin_scale_x = (float)(2.0 * (e + g) * 1.0001);
   a.margin_const = (float)(2.0 * (2.0 * e + g) * cmax * 1.0001);
   a.namb = ws.namb.p;
   const int ng = (int)((d + 7) / 8);
+  const int ngb = 2 * (int)((d + 15) / 16);  // bf16 kernels: dims padded to 16
+  if (bf16) {
+    const uint64_t ntiles = (k + 63) / 64, nc = ngb / 2;
+    VI_TRY(ws.img.reserve(ntiles * ngb * 2 * 64 * 4));  // uint32 words: 2*NG float4-sized pieces of 64 per tile
+    VI_TRY(ws.cnpad.reserve(ntiles * 64));
+    const uint64_t nt = ntiles * nc * 128;
+    hipLaunchKernelGGL(centroid_image_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Cd, (uint32_t)k, d,
+                       (uint32_t)nc, (uint4 *)ws.img.p);
+    hipLaunchKernelGGL(centroid_norm_pad_kernel, dim3((uint32_t)((ntiles * 64 + 255) / 256)), dim3(256), 0, st, ws.cn.p,
+                       (uint32_t)k, (uint32_t)(ntiles * 64), ws.cnpad.p);
+    VI_HIP(hipGetLastError());
+    a.img = (const float4 *)ws.img.p;
+    a.cn = ws.cnpad.p;
+  }
   uint64_t total_amb = 0;
   float ms_filter = 0.0f;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -263,7 +423,18 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     VI_HIP(hipMemsetAsync(ws.namb.p, 0, sizeof(uint32_t), st));
     a.X = Xd + p0 * d; a.n = (uint32_t)m; a.label = labels_dev + p0; a.amb_list = ws.amb_list.p;
     if (stats) VI_HIP(hipEventRecord(ev0, st));
-    if (ng <= 4) VI_TRY((launch_mfma<4, 2>(a, st)));
+    if (bf16) {
+      switch (ngb) {
+        case 2: VI_TRY(launch_mfma_bf16<2>(a, st)); break;
+        case 4: VI_TRY(launch_mfma_bf16<4>(a, st)); break;
+        case 6: VI_TRY(launch_mfma_bf16<6>(a, st)); break;
+        case 8: VI_TRY(launch_mfma_bf16<8>(a, st)); break;
+        case 10: VI_TRY(launch_mfma_bf16<10>(a, st)); break;
+        case 12: VI_TRY(launch_mfma_bf16<12>(a, st)); break;
+        case 14: VI_TRY(launch_mfma_bf16<14>(a, st)); break;
+        default: VI_TRY(launch_mfma_bf16<16>(a, st)); break;
+      }
+    } else if (ng <= 4) VI_TRY((launch_mfma<4, 2>(a, st)));
     else if (ng <= 8) VI_TRY((launch_mfma<8, 1>(a, st)));
     else if (ng <= 12) VI_TRY((launch_mfma<12, 1>(a, st)));
     else VI_TRY((launch_mfma<16, 1>(a, st)));  // 128 dims: 2 x 32 points would not fit 256 VGPRs

@@ -14,6 +14,8 @@ struct MfmaAssignStats {
 struct MfmaAssignWs {
   DevBuf<float> cn;
   DevBuf<uint32_t> namb, amb_list;
+  DevBuf<uint32_t> img;   // bf16 hi/lo images of the centroid tiles
+  DevBuf<float> cnpad;    // centroid norms padded to whole tiles (+inf)
 };
 
 // Re-evaluates rows rows_dev[0..nrows) of X (row-major, device) exactly over all centroids and

@@ -46,6 +46,7 @@
 
 #include "device_index.hpp"
 #include "device_math.hpp"
+#include "mfma_bf16.hpp"
 #include "scan.hpp"
 #include "wave_select.hpp"
 
@@ -90,25 +91,6 @@ __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t ns
 // bf16 x 3 ranking: every stored value x is split as hi + lo with hi = bf16(x), lo = bf16(x - hi)
 // (|x - hi - lo| <= 2^-18 |x|); q.v ~ hi.hi + hi.lo + lo.hi on the bf16 matrix pipe (16x the f32 rate)
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ uint32_t bf16_rn(float x) {  // round-to-nearest-even, finite inputs
-  const uint32_t b = __float_as_uint(x);
-  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-  const uint32_t h0 = bf16_rn(x0), h1 = bf16_rn(x1);
-  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);  // exact
-  hi = h0 | (h1 << 16);
-  lo = bf16_rn(r0) | (bf16_rn(r1) << 16);
-}
-__device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, float scale, uint4 &hi, uint4 &lo) {
-  split_pair(scale * lo4.x, scale * lo4.y, hi.x, lo.x);
-  split_pair(scale * lo4.z, scale * lo4.w, hi.y, lo.y);
-  split_pair(scale * hi4.x, scale * hi4.y, hi.z, lo.z);
-  split_pair(scale * hi4.z, scale * hi4.w, hi.w, lo.w);
-}
-
 // f32 blocks [quad][64] float4 -> bf16 blocks [chunk of 16 dims][plane hi/lo][half of 8 dims][64] x 16 B: the
 // image a 32x32x16 MFMA wants (lane (j,h) reads the 8 consecutive dims 16c+8h.. of vector j as one ds_read_b128),
 // same bytes per block as the f32 form
@@ -219,18 +201,6 @@ struct FilterArgs {
 // followed by the block's 64 squared norms.  With NBUF = 2 the next block lands in the other buffer while
 // this one is multiplied (one barrier per block); with NBUF = 1 the load is exposed and hidden by the other
 // workgroups of the CU (3 per CU instead of 2).
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-
-template <int NG>
-__device__ __forceinline__ void tile_dma(float *tile, const float4 *src, const float *xn, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < NG / 2; ++i) {  // 2*NG quads of 1 KiB, round-robin over the 4 waves
-    const int qd = wave + 4 * i;
-    __builtin_amdgcn_global_load_lds(src + qd * kWave + lane, (lds_ptr_t)(tile + qd * 256), 16, 0, 0);
-  }
-  if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
-}
-
 // value with the element index e (0..31) in its 5 low mantissa bits: |packed - m| < 2^-18 |m|
 __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
   return __uint_as_float((__float_as_uint(m) & ~31u) | e);
@@ -319,7 +289,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
   const uint32_t bi = (a.tile_start[l] + chunk * nblk) * 256u + 128u * (uint32_t)h + jq_grp;
 
-  tile_dma<NG>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+  tile_dma_image<NG>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
@@ -328,7 +298,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
     if (NBUF == 2 && more)
-      tile_dma<NG>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+      tile_dma_image<NG>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                    a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
@@ -430,7 +400,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
     if (NBUF == 1) {
       __syncthreads();  // every wave is done reading the tile
       if (more)
-        tile_dma<NG>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+        tile_dma_image<NG>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                      a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,46 @@
+// mfma_bf16.hpp — bf16 x 3 split arithmetic shared by the MFMA ranking kernels (filter_search.hip,
+// assign_mfma.hip).  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|; a product a*b is
+// ranked as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (bf16 pairs multiply exactly in f32).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+__device__ __forceinline__ uint32_t bf16_rn(float x) {  // round-to-nearest-even, finite inputs
+  const uint32_t b = __float_as_uint(x);
+  return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+  const uint32_t h0 = bf16_rn(x0), h1 = bf16_rn(x1);
+  const float r0 = x0 - __uint_as_float(h0 << 16), r1 = x1 - __uint_as_float(h1 << 16);  // exact
+  hi = h0 | (h1 << 16);
+  lo = bf16_rn(r0) | (bf16_rn(r1) << 16);
+}
+// 8 consecutive values (two float4), scaled, -> packed hi / lo halves (operand of one lane)
+__device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, float scale, uint4 &hi, uint4 &lo) {
+  split_pair(scale * lo4.x, scale * lo4.y, hi.x, lo.x);
+  split_pair(scale * lo4.z, scale * lo4.w, hi.y, lo.y);
+  split_pair(scale * hi4.x, scale * hi4.y, hi.z, lo.z);
+  split_pair(scale * hi4.z, scale * hi4.w, hi.w, lo.w);
+}
+
+// Image of 64 vectors for the A operand: [chunk of 16 dims][plane hi/lo][half of 8 dims][64 vectors] x 16 B
+// (lane (j, h) reads the 8 consecutive dims 16c+8h.. of vector j with one conflict-free ds_read_b128);
+// 2*NG KiB per 64 vectors when the dims are padded to 8*NG, the same bytes as the f32 values.
+// tile_dma_image copies one image + the 64 squared norms behind it into LDS with LDS-DMA, 4 waves.
+template <int NG>
+__device__ __forceinline__ void tile_dma_image(float *tile, const float4 *src, const float *xn, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NG / 2; ++i) {  // 2*NG pieces of 1 KiB, round-robin over the 4 waves
+    const int piece = wave + 4 * i;
+    __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, (lds_ptr_t)(tile + piece * 256), 16, 0, 0);
+  }
+  if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
+}
+
+}  // namespace vi
