@@ -283,10 +283,15 @@ def main():
         tf = flops / (best[1] * 1e-3) / 1e12
         kmeans = {"workload": f"exact nearest-centroid assign N={n3} D={d3} k={k3} (BASELINE config C3), one full pass",
                   "ms_total": round(best[0], 2), "ms_mfma_filter": round(best[1], 2), "ambiguous_rows_rechecked": best[2],
-                  "roofline": {"kernel": "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                               "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-                               "flops_per_launch": flops},
+                  "roofline": ({"kernel": "mfma_assign_bf16_kernel<16> (v_mfma_f32_32x32x16_bf16, operands split hi+lo: 3 "
+                                          "products per multiply)", "bound": "mfma", "achieved": round(tf, 1),
+                                "peak": round(MFMA_BF16_PEAK_TF / 3.0, 1), "unit": "TFLOP/s",
+                                "frac": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4), "flops_per_launch": flops,
+                                "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply"}
+                               if os.environ.get("VI_ASSIGN_BF16", "1") != "0" else
+                               {"kernel": "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                                "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops}),
                   "hbm_GBps": round((4.0 * n3 * d3 + 4.0 * n3) / (best[1] * 1e-3) / 1e9, 1),
                   "note": "labels are bit-identical to assign_points_brute_force: rows whose MFMA margin is not "
                           "provably safe are re-evaluated in the reference's exact summation order"}

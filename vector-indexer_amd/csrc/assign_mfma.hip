@@ -355,6 +355,19 @@ vi_status launch_mfma_bf16(const MfmaArgs &a, hipStream_t st) {
   return VI_OK;
 }
 
+__global__ void gather_amb_rows_kernel(const float *X, const uint32_t *rows, uint32_t nrows, uint32_t d, float *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread (d % 4 == 0)
+  const uint32_t q4 = d / 4;
+  if (t >= (uint64_t)nrows * q4) return;
+  const uint32_t i = (uint32_t)(t / q4), c = (uint32_t)(t % q4);
+  reinterpret_cast<float4 *>(out)[t] = reinterpret_cast<const float4 *>(X + (size_t)rows[i] * d)[c];
+}
+
+__global__ void scatter_amb_labels_kernel(const uint32_t *rows, uint32_t nrows, const uint32_t *lab_c, uint32_t *labels) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nrows) labels[rows[i]] = lab_c[i];
+}
+
 template <int NG, int NP>
 vi_status launch_mfma(const MfmaArgs &a, hipStream_t st) {
   const size_t smem = 2 * kTileFloats * sizeof(float);
@@ -364,6 +377,13 @@ vi_status launch_mfma(const MfmaArgs &a, hipStream_t st) {
   hipLaunchKernelGGL((mfma_assign_kernel<NG, NP>), dim3((a.n + ppb - 1) / ppb), dim3(256), smem, st, a);
   VI_HIP(hipGetLastError());
   return VI_OK;
+}
+
+vi_status launch_mfma_f32(const MfmaArgs &a, int ng, hipStream_t st) {
+  if (ng <= 4) return launch_mfma<4, 2>(a, st);
+  if (ng <= 8) return launch_mfma<8, 1>(a, st);
+  if (ng <= 12) return launch_mfma<12, 1>(a, st);
+  return launch_mfma<16, 1>(a, st);  // 128 dims: 2 x 32 points would not fit 256 VGPRs
 }
 
 }  // namespace
@@ -391,6 +411,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   static const bool bf16 = [] { const char *e = getenv("VI_ASSIGN_BF16"); return !(e && *e == '0'); }();
   const double u = 1.01 * std::ldexp(1.0, -24);
   const double e = bf16 ? (3.0 * d + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (d + 2.0) * u;
+  const double e32 = (d + 2.0) * u;
   const double g = (d / 8.0 + 8.0) * u * 2.0;
   MfmaArgs a{};
   a.X = Xd; a.dim = d; a.C = Cd; a.cn = ws.cn.p; a.k = (uint32_t)k;
@@ -412,7 +433,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     a.img = (const float4 *)ws.img.p;
     a.cn = ws.cnpad.p;
   }
-  uint64_t total_amb = 0;
+  uint64_t total_amb = 0, total_tier2 = 0;
   float ms_filter = 0.0f;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (stats) { VI_HIP(hipEventCreate(&ev0)); VI_HIP(hipEventCreate(&ev1)); }
@@ -434,23 +455,49 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
         case 14: VI_TRY(launch_mfma_bf16<14>(a, st)); break;
         default: VI_TRY(launch_mfma_bf16<16>(a, st)); break;
       }
-    } else if (ng <= 4) VI_TRY((launch_mfma<4, 2>(a, st)));
-    else if (ng <= 8) VI_TRY((launch_mfma<8, 1>(a, st)));
-    else if (ng <= 12) VI_TRY((launch_mfma<12, 1>(a, st)));
-    else VI_TRY((launch_mfma<16, 1>(a, st)));  // 128 dims: 2 x 32 points would not fit 256 VGPRs
+    } else {
+      VI_TRY(launch_mfma_f32(a, ng, st));
+    }
     if (stats) VI_HIP(hipEventRecord(ev1, st));
     uint32_t namb = 0;
     VI_HIP(hipMemcpyAsync(&namb, ws.namb.p, 4, hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
     if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1); ms_filter += ms; }
-    if (namb) {
+    if (namb && bf16 && namb >= 2048) {
+      // second tier: the bf16 margin is ~5x the f32 one, so most of its ambiguous rows are decided by the f32
+      // MFMA kernel on the gathered rows; only what that leaves goes through the exact-order scan
+      VI_TRY(ws.xc.reserve((uint64_t)namb * d));
+      VI_TRY(ws.lab_c.reserve(namb));
+      VI_TRY(ws.amb_list2.reserve(namb));
+      VI_TRY(ws.namb2.reserve(1));
+      const uint64_t nt = (uint64_t)namb * (d / 4);
+      hipLaunchKernelGGL(gather_amb_rows_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Xd + p0 * d,
+                         ws.amb_list.p, namb, d, ws.xc.p);
+      VI_HIP(hipGetLastError());
+      VI_HIP(hipMemsetAsync(ws.namb2.p, 0, sizeof(uint32_t), st));
+      MfmaArgs b = a;
+      b.X = ws.xc.p; b.n = namb; b.label = ws.lab_c.p; b.amb_list = ws.amb_list2.p; b.namb = ws.namb2.p; b.cn = ws.cn.p;
+      b.margin_scale_x = (float)(2.0 * (e32 + g) * 1.0001);
+      b.margin_const = (float)(2.0 * (2.0 * e32 + g) * cmax * 1.0001);
+      VI_TRY(launch_mfma_f32(b, ng, st));
+      uint32_t namb2 = 0;
+      VI_HIP(hipMemcpyAsync(&namb2, ws.namb2.p, 4, hipMemcpyDeviceToHost, st));
+      VI_HIP(hipStreamSynchronize(st));
+      if (namb2) VI_TRY(exact(exact_ctx, ws.xc.p, ws.amb_list2.p, namb2, ws.lab_c.p));
+      hipLaunchKernelGGL(scatter_amb_labels_kernel, dim3((namb + 255) / 256), dim3(256), 0, st, ws.amb_list.p, namb,
+                         ws.lab_c.p, labels_dev + p0);
+      VI_HIP(hipGetLastError());
+      total_amb += namb2;
+      total_tier2 += namb;
+    } else if (namb) {
       // exact-order re-evaluation of the ambiguous rows over ALL centroids
       VI_TRY(exact(exact_ctx, Xd + p0 * d, ws.amb_list.p, namb, labels_dev + p0));
+      total_amb += namb;
     }
-    total_amb += namb;
   }
   if (stats) {
     stats->ambiguous_rows = total_amb;
+    stats->tier2_rows = total_tier2;
     stats->ms_filter = ms_filter;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -8,6 +8,7 @@ namespace vi {
 
 struct MfmaAssignStats {
   uint64_t ambiguous_rows = 0;  // rows re-evaluated by the exact-order scan
+  uint64_t tier2_rows = 0;      // rows the bf16 pass left to the f32 MFMA pass
   float ms_filter = 0.0f;       // HIP-event time of the MFMA kernel launches
 };
 
@@ -16,6 +17,8 @@ struct MfmaAssignWs {
   DevBuf<uint32_t> namb, amb_list;
   DevBuf<uint32_t> img;   // bf16 hi/lo images of the centroid tiles
   DevBuf<float> cnpad;    // centroid norms padded to whole tiles (+inf)
+  DevBuf<float> xc;       // second tier: gathered ambiguous rows, their labels, what stays ambiguous
+  DevBuf<uint32_t> lab_c, amb_list2, namb2;
 };
 
 // Re-evaluates rows rows_dev[0..nrows) of X (row-major, device) exactly over all centroids and
