@@ -11,7 +11,7 @@ of NQ queries that are already resident in HBM.  value = queries/s over the time
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same index is partitioned by
-shard over the ranks (shard % N == rank), every rank searches the full query batch against the
+block over the ranks (block b of every list on rank b % N), every rank searches the full query batch against the
 lists it owns, the per-rank top-k are exchanged with ONE all-gather over RCCL and merged with the
 reference's stable candidate order.  Total work is fixed => "scaling": "strong".
 
@@ -124,11 +124,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    # rehearsal on a one-GPU box: VI_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and exchanges over gloo (RCCL
+    # refuses two ranks on one device); the driver's real N-GPU runs use one GPU per rank and RCCL
+    rehearsal = os.environ.get("VI_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import vector_indexer_py as vip
     from vector_indexer_py import _native
@@ -326,7 +334,7 @@ def main():
                "config": {"workload": f"IVF search N={args.n} D={args.d} nlist={args.nlist} nprobe={chosen} k={k} "
                                       f"nq/step={nq}", "nprobe": chosen, "recall": sweep[chosen],
                           "nprobe_sweep": sweep, "index_centroids": index.num_centroids, "build_s": round(build_s, 1),
-                          "parallelism": f"lists sharded over {world} GPU(s), coarse table replicated"
+                          "parallelism": f"every list striped over {world} GPU(s) (block b on rank b % N), coarse table replicated"
                                          + (", RCCL all-gather of per-rank top-k" if world > 1 else "")},
                "roofline": roofline, "cpu_baseline": cpu, "kmeans_assign": kmeans}
         print(json.dumps(out), flush=True)

@@ -144,8 +144,8 @@ typedef struct vi_config {
   uint64_t seed;            /* 0 => 42 (api.rs:143,183) */
   int32_t assign_mode;      /* vi_assign_mode for the build's final assignment */
   int32_t device;           /* HIP device ordinal */
-  /* multi-GPU partition: this process keeps only the inverted lists of shards s with
-   * s % world_size == rank resident (coarse table replicated).  world_size 0/1 => all. */
+  /* multi-GPU partition: this process keeps a stripe of every inverted list resident (block b of 64 vectors
+   * lives on rank b % world_size; coarse table replicated).  world_size 0/1 => everything. */
   int32_t rank;
   int32_t world_size;
   uint64_t now_secs;        /* 0 => wall clock; else value used for timestamp==0 records

@@ -1093,8 +1093,9 @@ int orc_index_search(const orc_index *ix, const float *q, uint64_t k, uint64_t n
   return rc;
 }
 
-/* Multi-GPU protocol checker: the search of rank `rank` of `world` (lists of shards
- * s % world == rank only), with the GLOBAL candidate-order key of every hit:
+/* Multi-GPU protocol checker (the placement is an extension: the reference has no device notion): the search
+ * of rank `rank` of `world`, which keeps block b (64 vectors) of every list iff b % world == rank, with the
+ * GLOBAL candidate-order key of every hit:
  * tie = (rank of the probe in the reference candidate order << 32) | position in list.
  * Merging the per-rank outputs by (dist, tie) must reproduce orc_index_search. */
 int orc_index_search_partial(const orc_index *ix, const float *q, uint64_t k, uint64_t n_probe,
@@ -1125,9 +1126,9 @@ int orc_index_search_partial(const orc_index *ix, const float *q, uint64_t k, ui
       uint64_t c = cd[i].idx;
       if (ix->c2s[c] != shard_order[si]) continue;
       uint64_t my_g = g++;
-      if (world > 1 && (ix->c2s[c] % world) != rank) continue;
       if (!ix->list_ok[c]) continue;
       for (uint64_t v = 0; v < ix->list_len[c]; ++v) {
+        if (world > 1 && ((v / 64) % world) != rank) continue;
         cs[nc].dist = orc_l2sq_scalar(q, ix->list_vec[c] + v * d, d);
         cs[nc].order = (uint32_t)nc; cs[nc].list = c; cs[nc].pos = v;
         ties[nc] = (my_g << 32) | v;

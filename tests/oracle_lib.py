@@ -276,6 +276,9 @@ class OracleIndex:
     def num_shards(self):
         return lib().orc_index_num_shards(self.h)
 
+    def list_len(self, c):
+        return int(lib().orc_index_list_len(self.h, c))
+
     def centroids(self):
         k, d = self.num_centroids, self.dimension
         Cn = np.zeros((k, d), dtype=np.float32)

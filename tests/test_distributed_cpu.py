@@ -1,4 +1,4 @@
-"""CPU (gloo, world_size 2): the multi-GPU search protocol — partition by shard, all-gather of per-rank
+"""CPU (gloo, world_size 2): the multi-GPU search protocol — every list striped over the ranks, all-gather of per-rank
 top-k, merge on (dist, tie) — reproduces the single-index result.  The per-rank searcher is the
 oracle's partial search (the GPU kernels are covered by the -m gpu tests)."""
 import os
@@ -23,12 +23,12 @@ def _worker(rank, world, port, work, out_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [os.path.join(root, "tests"), os.path.join(root, "vector-indexer_amd")]
     import oracle_lib as O
-    from vector_indexer_py.distributed import ShardedSearcher, merge_partials_reference, shard_owner
+    from vector_indexer_py.distributed import ShardedSearcher, merge_partials_reference, block_owner
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
     _, c2s = orc.centroids()
-    assert all(shard_owner(s, world) == int(s) % world for s in c2s)
+    assert [block_owner(b, world) for b in range(5)] == [b % world for b in range(5)]
     Q = np.load(os.path.join(work, "q.npy"))
 
     def local_search(xq, k, n_probe):

@@ -83,6 +83,7 @@ struct DeviceIndex {
   DevBuf<uint32_t> list_len;          // [nlists]  (0 => not resident here / empty)
   DevBuf<uint32_t> list_shard;        // [nlists]
   DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
+  uint32_t stripe_rank = 0, stripe_world = 1;  // multi-GPU: block b of a list lives on rank b % world
   DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (3e38 on pad slots)
   DevBuf<uint32_t> lists_bf16, cent_bf16;  // bf16 hi/lo images of the blocks for the MFMA ranking (filter_search.hip)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
@@ -99,7 +100,7 @@ struct DeviceIndex {
   ~DeviceIndex();
 };
 
-// Upload: centroid table + resident lists (shards with shard % world == rank), repacked on the GPU.
+// Upload: centroid table + this rank's stripe of every list (block b on rank b % world), repacked on the GPU.
 vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir, int device, int rank,
                             int world, DeviceIndex *out);
 

@@ -790,7 +790,12 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
                          dim * 4, 0, -1, ix->centroids.blocks.p, nullptr, ix->stream));
   }
 
-  // ---- lists: open the shard files this rank owns ----
+  // ---- lists: every rank maps all shard files and keeps a STRIPE of every list resident: block b (64 vectors)
+  //      of a list lives on rank b % world.  Placement of whole lists (or whole shard files, the reference's
+  //      grouping) cannot balance: on the bench workload two lists carry 52 % of the scan work, and the
+  //      reference's super-k-means puts neighbouring lists into one shard (92 % / 8 % of the work at world 2).
+  //      With stripes every rank scans 1/world of every probed list whatever the skew.  A local position p maps
+  //      back to the list position ((p / 64) * world + rank) * 64 + p % 64 (tie keys, stripe_tie_kernel). ----
   uint64_t nshards = 0;
   for (uint64_t c = 0; c < k; ++c) nshards = std::max(nshards, meta.c2s[c] + 1);
   ix->nshards = nshards;
@@ -800,7 +805,6 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
   const bool part = world > 1;
   uint64_t total_blocks = 0, total_vec = 0;
   for (uint64_t s = 0; s < nshards; ++s) {
-    if (part && (int)(s % (uint64_t)world) != rank) continue;
     auto f = std::make_unique<ShardFile>();
     // a missing/corrupt shard is skipped, as search does (`if let Ok`, ivf_index.rs:253-254)
     if (f->open(shards_dir, s) != VI_OK || f->dim() != dim) continue;
@@ -812,14 +816,25 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
     const ShardListView *lv = files[s]->find(c);
     if (!lv) { files[s].reset(); continue; }  // NotFound fails the whole shard read (shards.rs:257-265)
   }
+  const uint32_t W = part ? (uint32_t)world : 1u, R = part ? (uint32_t)rank : 0u;
+  ix->stripe_world = W;
+  ix->stripe_rank = R;
+  // this rank's blocks of a list of n vectors: b = R, R+W, ... ; the last block of the list may be partial
+  auto local_blocks = [&](uint32_t n) { const uint32_t nb = (n + kWave - 1) / kWave; return nb > R ? (nb - R + W - 1) / W : 0u; };
+  auto local_len = [&](uint32_t n) {
+    const uint32_t nb = (n + kWave - 1) / kWave, lb = local_blocks(n);
+    if (lb == 0) return 0u;
+    const uint32_t last = R + (lb - 1) * W;  // this rank's last block
+    return (lb - 1) * kWave + (last == nb - 1 ? n - last * kWave : (uint32_t)kWave);
+  };
   for (uint64_t c = 0; c < k; ++c) {
     const uint64_t s = meta.c2s[c];
     if (s >= nshards || !files[s]) continue;
     const ShardListView *lv = files[s]->find(c);
     h_first[c] = (uint32_t)total_blocks;
-    h_len[c] = lv->num_vectors;
-    total_blocks += (lv->num_vectors + kWave - 1) / kWave;
-    total_vec += lv->num_vectors;
+    h_len[c] = local_len(lv->num_vectors);
+    total_blocks += local_blocks(lv->num_vectors);
+    total_vec += h_len[c];
   }
   if (total_blocks >= 0xFFFFFFFFull / kWave) return fail(VI_ERR_OTHER, "index too large for 32-bit slot ids");
   ix->nvec_resident = total_vec;
@@ -846,10 +861,10 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
       const ShardListView &lv = f.list(i);
       if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0) continue;
       const uint32_t nb = (lv.num_vectors + kWave - 1) / kWave;
-      for (uint32_t b = 0; b < nb; ++b) {
+      for (uint32_t b = R; b < nb; b += W) {
         src.push_back((uint64_t)(lv.records - lo) + (uint64_t)b * kWave * stride);
         nv.push_back(std::min<uint32_t>(kWave, lv.num_vectors - b * kWave));
-        dst.push_back(h_first[lv.centroid_id] + b);
+        dst.push_back(h_first[lv.centroid_id] + (b - R) / W);
       }
     }
     VI_TRY(repack_upload(lo, (size_t)(hi - lo), src, nv, dst, dim, dq, stride, (uint32_t)kVectorMetaBytes, 8,
@@ -1075,6 +1090,17 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
 // ------------------------------------------------------------------------------------------
 // search pipeline (fast path: n_probe_eff <= 64 and k <= 64)
 // ------------------------------------------------------------------------------------------
+// striped lists: local position -> position in the whole list, so that the merge over ranks sees the
+// reference's candidate order
+__global__ void stripe_tie_kernel(uint64_t *tie, uint64_t n, uint32_t rank, uint32_t world) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t t = tie[i];
+  if (t == ~0ull) return;
+  const uint32_t p = (uint32_t)t;
+  tie[i] = (t & 0xFFFFFFFF00000000ull) | (uint64_t)(((p >> 6) * world + rank) * 64u + (p & 63u));
+}
+
 vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   std::lock_guard<std::mutex> lock(ix.mu);
   VI_HIP(hipSetDevice(ix.device));
@@ -1135,6 +1161,11 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     VI_TRY(search_valu_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing));
   }
 
+  if (ix.stripe_world > 1 && Td) {
+    hipLaunchKernelGGL(stripe_tie_kernel, dim3((uint32_t)((nq * k + 255) / 256)), dim3(256), 0, st, Td, nq * k,
+                       ix.stripe_rank, ix.stripe_world);
+    VI_HIP(hipGetLastError());
+  }
   // ---- results ----
   if (!io.on_device) {
     VI_HIP(hipMemcpyAsync(io.D, Dd, nq * k * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -1,6 +1,6 @@
-"""Multi-GPU search: one process per GPU, inverted lists partitioned by shard, ONE all-gather.
+"""Multi-GPU search: one process per GPU, every inverted list striped over the ranks, ONE all-gather.
 
-Rank r keeps the lists of shards s with s % world == r resident (vi_config.rank/world_size); the
+Rank r keeps block b (64 vectors) of every list iff b % world == r (vi_config.rank/world_size); the
 coarse table is replicated so every rank derives the same probe list and the same candidate-order
 keys.  Per query each rank returns its local top-k (D, I, tie); the three arrays are exchanged with
 torch.distributed.all_gather (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU
@@ -12,9 +12,12 @@ src/ivf_index.rs:104-164); this is the MI355X-native extension BASELINE.json's n
 import numpy as np
 
 
-def shard_owner(shard_id: int, world: int) -> int:
-    """placement rule shared by vi_indexer_load (csrc/search_kernels.hip) and the tests"""
-    return int(shard_id) % max(int(world), 1)
+def block_owner(block: int, world: int) -> int:
+    """placement rule shared by vi_indexer_load (csrc/search_kernels.hip) and the oracle's protocol checker: block b
+    (vectors 64b .. 64b+63) of EVERY list lives on rank b % world.  Stripes, not whole lists or shard files: the scan
+    work is concentrated in a few huge lists (two lists carry half of it on the bench index), which no placement of
+    whole lists can balance."""
+    return int(block) % max(int(world), 1)
 
 
 class ShardedSearcher:
