@@ -252,3 +252,72 @@ def test_mfma_filter_duplicates_reevaluate_whole_groups(tmp_path, monkeypatch):
     st = gpu.last_stats()
     assert st["filter_accepted"] > 0          # records whose 4th value ties the threshold: whole groups re-evaluated
     assert st["fallback_queries"] == 0
+
+
+class _Hip:
+    """device buffers through the HIP runtime the library itself is linked against (no torch in this process:
+    a second HIP runtime initialised after the library's does not see the GPU)"""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), max(int(nbytes), 1)) == 0
+        self.bufs.append(p)
+        return p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.alloc(a.nbytes)
+        assert self.rt.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert self.rt.hipDeviceSynchronize() == 0
+        assert self.rt.hipMemcpy(out.ctypes.data, p, out.nbytes, 2) == 0
+        return out
+
+    def close(self):
+        for p in self.bufs:
+            self.rt.hipFree(p)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_striped_ranks_merge_to_the_single_gpu_result(world, tmp_path, monkeypatch):
+    """Multi-GPU protocol through the C ABI on ONE device: the index loaded as rank r of `world` keeps block b of
+    every list iff b % world == r; the per-rank (D, I, tie) merged by vi_merge_partials_device must equal the
+    oracle's full search bit for bit — on both engines (the striped lists go through the MFMA path too)."""
+    from vector_indexer_py import _native
+    rng = np.random.default_rng(11)
+    base = rng.integers(-3, 4, size=(6000, 16)).astype(np.float32)      # integer grid: masses of exact ties
+    X = np.concatenate([base, base[:1500]])
+    orc, full = oracle_and_gpu(tmp_path, X, nlist=24)
+    Q = np.concatenate([base[:200], rng.integers(-3, 4, size=(120, 16)).astype(np.float32)])
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    parts = [vip.load(idx, sh, X.shape[1], rank=r, world_size=world) for r in range(world)]
+    hip = _Hip()
+    try:
+        nq = Q.shape[0]
+        xq = hip.upload(Q)
+        for engine in ("1", "0"):
+            monkeypatch.setenv("VI_FILTER", engine)
+            for k, n_probe in [(10, 6), (3, 24), (32, 2)]:
+                Dg, Ig, Tg = hip.alloc(world * nq * k * 4), hip.alloc(world * nq * k * 8), hip.alloc(world * nq * k * 8)
+                for r, p in enumerate(parts):
+                    p.search_device(xq, nq, k, n_probe, Dg + r * nq * k * 4, Ig + r * nq * k * 8, Tg + r * nq * k * 8)
+                Dm, Im = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+                _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+                rc, Do, Io = orc.search_batch(Q, k, n_probe)
+                assert rc == O.ORC_OK
+                assert (hip.download(Im, (nq, k), np.int64) == Io).all(), (engine, k, n_probe)
+                assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), (engine, k, n_probe)
+    finally:
+        hip.close()
