@@ -19,6 +19,15 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+@pytest.fixture(params=["default-engine", "valu-engine"], autouse=True)
+def _engine(request, monkeypatch):
+    """every test of this file runs twice: with the library's own engine choice (the MFMA path wherever it
+    applies) and with the exact-order VALU engine forced; tests that set VI_FILTER themselves override this"""
+    if request.param == "valu-engine":
+        monkeypatch.setenv("VI_FILTER", "0")
+    yield
+
+
 def oracle_and_gpu(tmp_path, X, nlist=0, ext_ids=None, seed=42):
     idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
     orc = O.OracleIndex.build(X, idx, sh, ext_ids=ext_ids, nlist=nlist, seed=seed)
