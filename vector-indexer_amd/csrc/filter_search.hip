@@ -1,5 +1,6 @@
-// filter_search.hip — list scan and coarse quantizer on the matrix cores: f32-MFMA ranking +
-// exact-order re-evaluation of the few vectors that can be results.
+// filter_search.hip — list scan and coarse quantizer on the matrix cores: MFMA ranking (bf16 x 3 split
+// arithmetic by default, f32 MFMA with VI_FILTER_BF16=0) + exact-order re-evaluation of the few vectors
+// that can be results.
 //
 // The exact-order VALU scan (search_kernels.hip) spends 3 vector ops per (query, vector, dim) and is
 // bound by f32 VALU issue.  When many queries of a batch probe the same list, (queries x vectors x
@@ -7,8 +8,9 @@
 // reach the top-k need the reference's exact arithmetic (src/utils.rs:28-30).
 //
 //   1. rank      per work item (list segment of <= segb blocks, group of <= 128 queries):
-//                m(q,v) = ||v||^2 - 2 q.v with v_mfma_f32_32x32x2_f32 (A = 64 vectors staged in LDS,
-//                B = the group's queries in registers, accumulator initialised with ||v||^2).
+//                m(q,v) = ||v||^2 - 2 q.v on the matrix cores (A = 64 vectors staged in LDS, B = the group's
+//                queries in registers, accumulator initialised with ||v||^2): v_mfma_f32_32x32x16_bf16 on
+//                operands split hi + lo (hi.hi + hi.lo + lo.hi, mfma_bf16.hpp), or v_mfma_f32_32x32x2_f32.
 //                A lane owns one query and 32 of the 64 rows of every block (a "lane-block").  Per
 //                block it keeps the four smallest values b1 <= .. <= b4 of its 32 (the row index
 //                rides in the 5 low mantissa bits, so min/med3 carry it for free) and stores them
@@ -20,7 +22,7 @@
 //                With m_K the K-th smallest recorded value, every vector of the true top-K has
 //                    m <= thr = m_K + 2E + 3 gamma (m_K + ||q||^2 + E)            (*)
 //                    gamma = (D+2) u'                      rounding of the reference's sequential sum
-//                    E     = ((D+2) u' + 2^-18)(||q||^2 + 2 max||v||^2)   MFMA chain, norms, packed bits
+//                    E     = e (||q||^2 + 2 max||v||^2), e = rank arithmetic + packed bits (select_common)
 //                because the K recorded vectors below m_K already bound the K-th reference distance.
 //                What a record does not list is bounded by what it does:
 //                  - values dropped from T are >= T3, so T3 <= thr => every block record of the group
