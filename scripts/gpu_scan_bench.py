@@ -47,5 +47,6 @@ def run(label, n_probe, reps=6, **env):
 
 for p in (16,):
     run("default", p)
-    run("stats: list select", p, VI_FILTER_STATS=1)
-    run("stats: coarse select", p, VI_FILTER_STATS=2)
+    run("hi-only off", p, VI_FILTER_HI_ONLY=0)
+    run("no epilogue", p, VI_FILTER_XMODE=2)
+    run("no brec store", p, VI_FILTER_XMODE=8)

@@ -86,6 +86,7 @@ struct DeviceIndex {
   uint32_t stripe_rank = 0, stripe_world = 1;  // multi-GPU: block b of a list lives on rank b % world
   DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (3e38 on pad slots)
   DevBuf<uint32_t> lists_bf16, cent_bf16;  // bf16 hi/lo images of the blocks for the MFMA ranking (filter_search.hip)
+  bool lists_lo_zero = false, cent_lo_zero = false;  // every stored value is bf16-exact (lo planes all zero)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   DevBuf<float> cent_xnorm;           // same for the coarse table
   float cent_xmax2 = 0.0f;

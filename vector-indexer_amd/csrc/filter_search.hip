@@ -112,6 +112,16 @@ __global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nb
   dst[(1 * 2 + h) * 64 + v] = lo;
 }
 
+// any nonzero lo half in an image? (pieces of 64 uint4: plane = (piece >> 1) & 1)
+__global__ void lo_plane_any_kernel(const uint4 *img, uint64_t npieces, uint32_t *any) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npieces * 64) return;
+  const uint64_t piece = t >> 6;
+  if (((piece >> 1) & 1) == 0) return;
+  const uint4 v = img[t];
+  if (((v.x | v.y | v.z | v.w) & 0x7FFF7FFFu) != 0u) atomicOr(any, 1u);
+}
+
 // ------------------------------------------------------------------------------------------
 // record bookkeeping: where the records of (query, probe) start
 // ------------------------------------------------------------------------------------------
@@ -220,10 +230,31 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
     pos = c_ ? tp_ : pos;     \
   }
 
+// one block image -> LDS: all of it, or (RANK 2) only its hi planes: pieces (chunk c, plane 0, half h) = 4c + h
+template <int NG, int RANK>
+__device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, const float *xn, int wave, int lane) {
+  if constexpr (RANK != 2) {
+    tile_dma_image<NG>(tile, src, xn, wave, lane);
+  } else {
+#pragma unroll
+    for (int i0 = 0; i0 < NG; i0 += 4) {
+      const int i = i0 + wave;
+      if (i < NG) {
+        const int piece = 4 * (i >> 1) + (i & 1);
+        __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, (lds_ptr_t)(tile + piece * 256), 16, 0, 0);
+      }
+    }
+    if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
+  }
+}
+
 // NG = dq/2 exactly: a block holds 2*NG quads (dims padded to 16); dim % 4 == 0.  TABLE only names the instance
 // that ranks the centroid table (coarse step), so that profiles tell it from the list scan.
-// BF16: rank with three bf16 MFMAs per 16 dims (hi.hi + hi.lo + lo.hi) instead of eight f32 MFMAs.
-template <int NG, int NBUF, bool TABLE, bool BF16>
+// RANK 0: f32 MFMA (eight per 16 dims).  RANK 1: three bf16 MFMAs per 16 dims (hi.hi + hi.lo + lo.hi).
+// RANK 2: the stored values are bf16-exact (every lo plane is zero: 8-bit descriptors such as SIFT) — only the hi
+// planes are staged (half the bytes) and lo.hi is dropped; hi.lo is dropped too for a wave whose 32 queries are
+// bf16-exact (wave-uniform test), which leaves ONE MFMA per 16 dims with the result still exact to f32 rounding.
+template <int NG, int NBUF, bool TABLE, int RANK>
 __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterArgs a) {
   constexpr int kTileFloats = 2 * NG * 256 + 64;
   __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
@@ -263,6 +294,8 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   const uint32_t qid = slot / a.P;
   const float *qrow = a.Q + (size_t)qid * a.dim;
   float4 qf[NG];  // f32: -2q, dims 8g+4h.. ; BF16: qf[2c] = hi, qf[2c+1] = lo halves (bit patterns) of -2q, dims 16c+8h..
+  constexpr bool BF16 = RANK != 0;
+  bool q_lo_zero = false;  // RANK 2: every query of this wave splits with lo = 0
   if constexpr (!BF16) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -283,6 +316,15 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
       qf[2 * c] = __builtin_bit_cast(float4, hi);
       qf[2 * c + 1] = __builtin_bit_cast(float4, lo);
     }
+    if constexpr (RANK == 2) {
+      uint32_t any = 0;
+#pragma unroll
+      for (int c = 0; c < NG / 2; ++c) {
+        const uint4 lo = __builtin_bit_cast(uint4, qf[2 * c + 1]);
+        any |= lo.x | lo.y | lo.z | lo.w;
+      }
+      q_lo_zero = __ballot((any & 0x7FFF7FFFu) != 0u) == 0ull;  // (-0 halves are zero too)
+    }
   }
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
@@ -291,7 +333,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
   // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
   const uint32_t bi = (a.tile_start[l] + chunk * nblk) * 256u + 128u * (uint32_t)h + jq_grp;
 
-  tile_dma_image<NG>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+  tile_dma_rank<NG, RANK>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
@@ -300,7 +342,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
     if (NBUF == 2 && more)
-      tile_dma_image<NG>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+      tile_dma_rank<NG, RANK>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                    a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
@@ -343,24 +385,56 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
         auto frag = [&](int c, int p, int t) {
           return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(s_tile + (((c * 2 + p) * 2 + h) * 64 + 32 * t + j) * 4));
         };
-        // hi fragments of chunk c+1 are requested while the lo MFMAs of chunk c run, lo fragments of chunk c while
-        // its hi MFMAs run: 16 fragment registers, every read has MFMAs to hide behind
-        bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
+        if constexpr (RANK == 1) {
+          // hi fragments of chunk c+1 are requested while the lo MFMAs of chunk c run, lo fragments of chunk c
+          // while its hi MFMAs run: 16 fragment registers, every read has MFMAs to hide behind
+          bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
 #pragma unroll
-        for (int c = 0; c < NG / 2; ++c) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
-          const bf16x8 l0 = frag(c, 1, 0), l1 = frag(c, 1, 1);
-          __builtin_amdgcn_sched_barrier(0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (c + 1 < NG / 2) { h0 = frag(c + 1, 0, 0); h1 = frag(c + 1, 0, 1); }
-          __builtin_amdgcn_sched_barrier(0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int c = 0; c < NG / 2; ++c) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
+            const bf16x8 l0 = frag(c, 1, 0), l1 = frag(c, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NG / 2) { h0 = frag(c + 1, 0, 0); h1 = frag(c + 1, 0, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, bh, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          // stored values are bf16-exact: hi planes only; hi fragments one chunk ahead
+          bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
+          if (q_lo_zero) {
+#pragma unroll
+            for (int c = 0; c < NG / 2; ++c) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]);
+              bf16x8 n0 = h0, n1 = h1;
+              if (c + 1 < NG / 2) { n0 = frag(c + 1, 0, 0); n1 = frag(c + 1, 0, 1); }
+              __builtin_amdgcn_sched_barrier(0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              h0 = n0; h1 = n1;
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < NG / 2; ++c) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
+              bf16x8 n0 = h0, n1 = h1;
+              if (c + 1 < NG / 2) { n0 = frag(c + 1, 0, 0); n1 = frag(c + 1, 0, 1); }
+              __builtin_amdgcn_sched_barrier(0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              h0 = n0; h1 = n1;
+            }
+          }
         }
       }
       if (!(a.xmode & 2u)) {
@@ -402,7 +476,7 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
     if (NBUF == 1) {
       __syncthreads();  // every wave is done reading the tile
       if (more)
-        tile_dma_image<NG>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+        tile_dma_rank<NG, RANK>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                      a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -872,34 +946,38 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
 }
 
 template <int NG>
-vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, bool bf16, hipStream_t st) {
+vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, hipStream_t st) {
   if (nitems == 0) return VI_OK;
   static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
   const bool table = a.qoff == nullptr;
-  if (bf16) {
-    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, true>), dim3(nitems), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, true>), dim3(nitems), dim3(256), 0, st, a);
+  const dim3 grid(nitems), block(256);
+  if (rank_mode == 2) {
+    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 2>), grid, block, 0, st, a);
+  } else if (rank_mode == 1) {
+    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
   } else if (table) {
-    hipLaunchKernelGGL((filter_kernel<NG, 1, true, false>), dim3(nitems), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0>), grid, block, 0, st, a);
   } else if (nbuf == 1) {
-    hipLaunchKernelGGL((filter_kernel<NG, 1, false, false>), dim3(nitems), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0>), grid, block, 0, st, a);
   } else {
-    hipLaunchKernelGGL((filter_kernel<NG, 2, false, false>), dim3(nitems), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((filter_kernel<NG, 2, false, 0>), grid, block, 0, st, a);
   }
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
 
-vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, bool bf16, hipStream_t st) {
+vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, int rank_mode, hipStream_t st) {
   switch (dq / 2) {  // dq is a multiple of 4
-    case 2: return launch_filter_t<2>(a, nitems, bf16, st);
-    case 4: return launch_filter_t<4>(a, nitems, bf16, st);
-    case 6: return launch_filter_t<6>(a, nitems, bf16, st);
-    case 8: return launch_filter_t<8>(a, nitems, bf16, st);
-    case 10: return launch_filter_t<10>(a, nitems, bf16, st);
-    case 12: return launch_filter_t<12>(a, nitems, bf16, st);
-    case 14: return launch_filter_t<14>(a, nitems, bf16, st);
-    case 16: return launch_filter_t<16>(a, nitems, bf16, st);
+    case 2: return launch_filter_t<2>(a, nitems, rank_mode, st);
+    case 4: return launch_filter_t<4>(a, nitems, rank_mode, st);
+    case 6: return launch_filter_t<6>(a, nitems, rank_mode, st);
+    case 8: return launch_filter_t<8>(a, nitems, rank_mode, st);
+    case 10: return launch_filter_t<10>(a, nitems, rank_mode, st);
+    case 12: return launch_filter_t<12>(a, nitems, rank_mode, st);
+    case 14: return launch_filter_t<14>(a, nitems, rank_mode, st);
+    case 16: return launch_filter_t<16>(a, nitems, rank_mode, st);
     default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
   }
 }
@@ -907,6 +985,12 @@ vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, bool 
 // rank arithmetic: bf16 x 3 unless VI_FILTER_BF16=0 (f32 MFMA)
 bool rank_bf16() {
   static const bool on = [] { const char *e = getenv("VI_FILTER_BF16"); return !(e && *e == '0'); }();
+  return on;
+}
+
+// RANK 2 (hi planes only when the stored values are bf16-exact) unless VI_FILTER_HI_ONLY=0
+bool hi_only_ok() {
+  static const bool on = [] { const char *e = getenv("VI_FILTER_HI_ONLY"); return !(e && *e == '0'); }();
   return on;
 }
 
@@ -988,7 +1072,23 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
       hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nt_c + 255) / 256)), dim3(256), 0, ix->stream,
                          (const float4 *)ix->centroids.blocks.p, ix->dq, ix->centroids.nblocks, (uint4 *)ix->cent_bf16.p);
     VI_HIP(hipGetLastError());
+    // bf16-exact stored values (8-bit descriptors): the lo planes are all zero and need not be streamed
+    uint32_t h_any[2] = {0u, 0u};
+    VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
+    const uint64_t np_l = ix->lists.nblocks * ix->dq, np_c = ix->centroids.nblocks * ix->dq;
+    if (np_l)
+      hipLaunchKernelGGL(lo_plane_any_kernel, dim3((uint32_t)((np_l * 64 + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const uint4 *)ix->lists_bf16.p, np_l, mx.p);
+    VI_HIP(hipMemcpyAsync(&h_any[0], mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
     VI_HIP(hipStreamSynchronize(ix->stream));
+    VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
+    if (np_c)
+      hipLaunchKernelGGL(lo_plane_any_kernel, dim3((uint32_t)((np_c * 64 + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const uint4 *)ix->cent_bf16.p, np_c, mx.p);
+    VI_HIP(hipMemcpyAsync(&h_any[1], mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    VI_HIP(hipStreamSynchronize(ix->stream));
+    ix->lists_lo_zero = np_l > 0 && h_any[0] == 0;
+    ix->cent_lo_zero = np_c > 0 && h_any[1] == 0;
   }
   const uint32_t one_first[1] = {0u}, one_len[1] = {(uint32_t)ix->nlists};
   VI_TRY(ix->c_first.reserve(1));
@@ -1040,7 +1140,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
-    VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16(), st));
+    VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, st));
   }
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
@@ -1127,7 +1227,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.item_list = ws.item_list.p;
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
-    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_bf16(), st));
+    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0, st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----
