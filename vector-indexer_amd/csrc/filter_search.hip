@@ -984,14 +984,14 @@ vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, int r
 
 // rank arithmetic: bf16 x 3 unless VI_FILTER_BF16=0 (f32 MFMA)
 bool rank_bf16() {
-  static const bool on = [] { const char *e = getenv("VI_FILTER_BF16"); return !(e && *e == '0'); }();
-  return on;
+  const char *e = getenv("VI_FILTER_BF16");
+  return !(e && *e == '0');
 }
 
 // RANK 2 (hi planes only when the stored values are bf16-exact) unless VI_FILTER_HI_ONLY=0
 bool hi_only_ok() {
-  static const bool on = [] { const char *e = getenv("VI_FILTER_HI_ONLY"); return !(e && *e == '0'); }();
-  return on;
+  const char *e = getenv("VI_FILTER_HI_ONLY");
+  return !(e && *e == '0');
 }
 
 SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2) {
