@@ -228,27 +228,41 @@ def main():
     common = {"algorithmic_bytes_per_launch": int(algo_bytes_rank), "avg_launch_ms": round(scan_s * 1000, 4),
               "coarse_ms": round(float(np.mean(coarse_ms)), 4), "pipeline_ms": round(float(np.mean(tot_ms)), 4)}
     if st["filter_tile_blocks"] > 0:
-        # MFMA path.  The list scan is a dense contraction (queries x list vectors x dims) ranked on the bf16 matrix
-        # pipe with the operands split hi+lo: 3 bf16 products per element pair (hi.hi, hi.lo, lo.hi).  Algorithmic
-        # flops = 2*D per (query, scanned vector) pair (multiply-add of the norm-expanded distance; SURVEY 8d's 3*D
-        # counts the reference's sub/mul/add, which this form does not execute).  Peak = bf16 dense peak / 3.
+        # MFMA path.  The list scan is a dense contraction (queries x list vectors x dims): one 64-vector block image
+        # staged in LDS is ranked against a group of <= 128 queries on the matrix cores.  Algorithmic flops = 2*D per
+        # (query, scanned vector) pair (multiply-add of the norm-expanded distance; SURVEY 8d's 3*D counts the
+        # reference's sub/mul/add, which this form does not execute).
         tiles = st["filter_tile_blocks"]
         dq = 4 * ((args.d + 15) // 16)
-        tile_bytes = tiles * (64 * dq * 16 + 256 * 16)  # one block image per 128-query group + its block records
+        mode = int(st["rank_mode"])  # 1 f32 MFMA, 2 bf16x3, 3 bf16 on hi planes only
         flops = 2.0 * args.d * st["scanned_vectors"]
         tf = flops / scan_s / 1e12 if scan_s > 0 else 0.0
-        peak = MFMA_BF16_PEAK_TF / 3.0
-        roofline = {"kernel": "filter_kernel<NG,1,false,true> (bf16x3 MFMA ranking of query-group x list-segment tiles)",
-                    "bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": None, "flops_per_launch": flops,
-                    "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply",
-                    "tiles_per_launch": int(tiles), "tile_bytes_per_launch": int(tile_bytes),
-                    "tile_stream_GBps": round(tile_bytes / scan_s / 1e9, 1) if scan_s > 0 else 0.0,
-                    "survey_accounting_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common,
-                    "note": "a staged 64-vector block serves up to 128 queries, so SURVEY 8d's no-reuse accounting "
-                            "(4*D+8 B per (query, scanned vector) = survey_accounting_GBps) is far above HBM; "
-                            "tile_stream_GBps is what the kernel's tiles pull through L2 (block image per query group "
-                            "+ block records), traffic is what PMC saw cross to HBM/MALL per launch"}
+        image = 64 * dq * (8 if mode == 3 else 16)       # bytes of one block image streamed per tile
+        tile_bytes = tiles * (image + 256 * 16)           # + 2 x 128 block records of 16 B per tile
+        stream = tile_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        extra = {"flops_per_launch": flops, "useful_TFLOPs": round(tf, 1), "tiles_per_launch": int(tiles),
+                 "tile_bytes_per_launch": int(tile_bytes), "tile_stream_GBps": round(stream, 1),
+                 "survey_accounting_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common}
+        if mode == 3:
+            # stored values are bf16-exact (8-bit descriptors): ONE bf16 MFMA per 16 dims, the matrix pipe is at
+            # ~15 % — what limits the kernel is the stream of tiles (hi image in, block records out) it must move.
+            roofline = {"kernel": "filter_kernel<NG,1,false,2> (bf16 MFMA ranking, hi planes only, of query-group x "
+                                  "list-segment tiles)", "bound": "hbm", "achieved": round(stream, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(stream / HBM_PEAK_GBS, 4), "traffic": None,
+                        "mfma_frac_of_bf16_peak": round(tf / MFMA_BF16_PEAK_TF, 4), **extra,
+                        "note": "achieved = bytes the kernel's decomposition must move per launch (one hi-plane block "
+                                "image per 128-query group + its block records) / launch time; traffic = what PMC saw "
+                                "cross to HBM/MALL (the query groups of a list re-read its blocks from L2/MALL); SURVEY "
+                                "8d's no-reuse accounting (4*D+8 B per (query, scanned vector)) is "
+                                "survey_accounting_GBps"}
+        else:
+            peak = MFMA_BF16_PEAK_TF / 3.0 if mode == 2 else MFMA_F32_PEAK_TF
+            roofline = {"kernel": ("filter_kernel<NG,1,false,1> (bf16x3 MFMA ranking" if mode == 2 else
+                                   "filter_kernel<NG,1,false,0> (f32 MFMA ranking") + " of query-group x list-segment tiles)",
+                        "bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "traffic": None,
+                        "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply" if mode == 2
+                                     else "f32 dense MFMA peak", **extra}
     else:
         roofline = {"kernel": "scan_kernel<LISTS> (inverted-list L2 scan + wave top-k)", "bound": "hbm",
                     "achieved": round(algo_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -214,10 +214,12 @@ typedef struct vi_search_stats {
   uint64_t scanned_vectors;    /* Σ over queries of Σ len(probed lists resident here) */
   uint64_t scan_items;         /* (list, query-group) work items of the list-scan kernel */
   float ms_total, ms_coarse, ms_group, ms_scan, ms_merge; /* HIP-event times on the search stream */
-  uint64_t fallback_queries;   /* queries the MFMA-filter path handed to the exact VALU pipeline */
-  uint64_t filter_tile_blocks; /* MFMA filter: (32-query tile, 64-vector block) products computed */
-  uint64_t filter_rechecked;   /* (query, vector) pairs that survived the filter and were re-evaluated exactly */
-  uint64_t filter_accepted;    /* of those, pairs with exact distance <= the query bound */
+  uint64_t fallback_queries;   /* always 0 (kept for ABI stability: the MFMA path has no fallback) */
+  uint64_t filter_tile_blocks; /* MFMA path: (128-query group, 64-vector block) tiles ranked; 0 on the VALU engine */
+  uint64_t filter_rechecked;   /* VI_FILTER_STATS=1: (query, vector) pairs re-evaluated in exact order */
+  uint64_t filter_accepted;    /* VI_FILTER_STATS=1: block records consulted */
+  uint64_t rank_mode;          /* list scan of the last search: 0 exact-order VALU engine, 1 f32 MFMA,
+                                  2 bf16 x 3 MFMA, 3 bf16 MFMA on hi planes only (bf16-exact stored values) */
 } vi_search_stats;
 /* stats of the most recent search on this handle (timing collected only if enabled) */
 vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out);

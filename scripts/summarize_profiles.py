@@ -17,7 +17,7 @@ shutil.copy(kt, f"profiles/{tag}_bench_kernel_stats.csv")
 
 
 # dominant kernel of the pipeline: the MFMA list ranking when the MFMA path ran, else the VALU list scan
-KERNEL = r"filter_kernel<\d+, \d+, false, (true|false)>|scan_kernel<\d+, 0, false, false>"
+KERNEL = r"filter_kernel<\d+, \d+, false, \d+>|scan_kernel<\d+, 0, false, false>"
 
 
 def scan_avg(pattern, counter):

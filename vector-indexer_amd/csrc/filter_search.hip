@@ -240,11 +240,11 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
     for (int i0 = 0; i0 < NG; i0 += 4) {
       const int i = i0 + wave;
       if (i < NG) {
-        const int piece = 4 * (i >> 1) + (i & 1);
-        __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, (lds_ptr_t)(tile + piece * 256), 16, 0, 0);
+        const int piece = 4 * (i >> 1) + (i & 1);  // hi piece i = 2c + h lands compactly at i
+        glds16_asm(src + piece * 64 + lane, tile + i * 256);
       }
     }
-    if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
+    if (wave == 0) glds4_asm(xn + lane, tile + NG * 256);  // (asm: the double-buffered loop places its own waits)
   }
 }
 
@@ -255,8 +255,9 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
 // planes are staged (half the bytes) and lo.hi is dropped; hi.lo is dropped too for a wave whose 32 queries are
 // bf16-exact (wave-uniform test), which leaves ONE MFMA per 16 dims with the result still exact to f32 rounding.
 template <int NG, int NBUF, bool TABLE, int RANK>
-__global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterArgs a) {
-  constexpr int kTileFloats = 2 * NG * 256 + 64;
+__global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_kernel(FilterArgs a) {
+  constexpr int kImage = (RANK == 2 ? NG : 2 * NG) * 256;  // floats of the staged image (RANK 2: hi planes only)
+  constexpr int kTileFloats = kImage + 64;                 // + the block's 64 norms
   __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -349,8 +350,8 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
       f32x16 acc0, acc1;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) live in regs 4*q4 .. 4*q4+3
-        const float4 n0 = *reinterpret_cast<const float4 *>(s_tile + 2 * NG * 256 + 8 * q4 + 4 * h);
-        const float4 n1 = *reinterpret_cast<const float4 *>(s_tile + 2 * NG * 256 + 32 + 8 * q4 + 4 * h);
+        const float4 n0 = *reinterpret_cast<const float4 *>(s_tile + kImage + 8 * q4 + 4 * h);
+        const float4 n1 = *reinterpret_cast<const float4 *>(s_tile + kImage + 32 + 8 * q4 + 4 * h);
         acc0[4 * q4 + 0] = n0.x; acc0[4 * q4 + 1] = n0.y; acc0[4 * q4 + 2] = n0.z; acc0[4 * q4 + 3] = n0.w;
         acc1[4 * q4 + 0] = n1.x; acc1[4 * q4 + 1] = n1.y; acc1[4 * q4 + 2] = n1.z; acc1[4 * q4 + 3] = n1.w;
       }
@@ -382,8 +383,9 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
       } else {
         // image: [chunk][plane][half][vector] x 16 B; fragment (plane p, tile t) of chunk c for lane (j,h) =
         // float4 index ((c*2 + p)*2 + h)*64 + 32t + j
-        auto frag = [&](int c, int p, int t) {
-          return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(s_tile + (((c * 2 + p) * 2 + h) * 64 + 32 * t + j) * 4));
+        auto frag = [&](int c, int p, int t) {  // RANK 2 stages the hi pieces compactly: piece 2c + h
+          const int piece = RANK == 2 ? 2 * c + h : (c * 2 + p) * 2 + h;
+          return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(s_tile + (piece * 64 + 32 * t + j) * 4));
         };
         if constexpr (RANK == 1) {
           // hi fragments of chunk c+1 are requested while the lo MFMAs of chunk c run, lo fragments of chunk c
@@ -406,34 +408,20 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-          // stored values are bf16-exact: hi planes only; hi fragments one chunk ahead
+          // stored values are bf16-exact: hi planes only
           bf16x8 h0 = frag(0, 0, 0), h1 = frag(0, 0, 1);
-          if (q_lo_zero) {
 #pragma unroll
-            for (int c = 0; c < NG / 2; ++c) {
-              const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]);
-              bf16x8 n0 = h0, n1 = h1;
-              if (c + 1 < NG / 2) { n0 = frag(c + 1, 0, 0); n1 = frag(c + 1, 0, 1); }
-              __builtin_amdgcn_sched_barrier(0);
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-              h0 = n0; h1 = n1;
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < NG / 2; ++c) {
-              const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
-              bf16x8 n0 = h0, n1 = h1;
-              if (c + 1 < NG / 2) { n0 = frag(c + 1, 0, 0); n1 = frag(c + 1, 0, 1); }
-              __builtin_amdgcn_sched_barrier(0);
-              acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+          for (int c = 0; c < NG / 2; ++c) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, qf[2 * c]), bl = __builtin_bit_cast(bf16x8, qf[2 * c + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bh, acc1, 0, 0, 0);
+            if (!q_lo_zero) {  // wave-uniform
               acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, bl, acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, bl, acc1, 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-              h0 = n0; h1 = n1;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NG / 2) { h0 = frag(c + 1, 0, 0); h1 = frag(c + 1, 0, 1); }  // requested behind the MFMAs
           }
         }
       }
@@ -478,9 +466,18 @@ __global__ void __launch_bounds__(256, NBUF == 1 ? 3 : 2) filter_kernel(FilterAr
       if (more)
         tile_dma_rank<NG, RANK>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                      a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // next tile visible
+    } else {
+      // The next tile's LDS-DMA was issued before this block's MFMAs; the only younger vector-memory operation
+      // is this wave's block-record store (vmcnt counts loads, stores and LDS-DMA together, in issue order).
+      // Waiting for all but that store keeps the store's latency off the critical path; __syncthreads() would
+      // insert vmcnt(0), hence the raw barrier (LDS reads of this tile are complete: lgkmcnt(0)).
+      if (wave_live && !(a.xmode & 10u)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // next tile visible; this tile free to be overwritten
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                     // next tile visible; this tile free to be overwritten
   }
   if (qlive) {
     const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
@@ -951,9 +948,9 @@ vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, h
   static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
   const bool table = a.qoff == nullptr;
   const dim3 grid(nitems), block(256);
-  if (rank_mode == 2) {
-    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 2>), grid, block, 0, st, a);
+  if (rank_mode == 2) {  // half-size tiles: two buffers fit where one full image did, the next tile loads during the MFMAs
+    if (table) hipLaunchKernelGGL((filter_kernel<NG, 2, true, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2>), grid, block, 0, st, a);
   } else if (rank_mode == 1) {
     if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
@@ -1227,7 +1224,9 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.item_list = ws.item_list.p;
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
-    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0, st));
+    const int rank_mode = rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0;
+    stt.rank_mode = (uint64_t)rank_mode + 1;
+    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_mode, st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----

@@ -43,4 +43,21 @@ __device__ __forceinline__ void tile_dma_image(float *tile, const float4 *src, c
   if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
 }
 
+// The same copies as inline asm.  hipcc does not count asm memory operations, so it inserts no s_waitcnt for them:
+// with the builtin it waits vmcnt(0) before the first ds_read that follows an LDS-DMA (it cannot tell that the read
+// touches the OTHER buffer), which serialises a double-buffered loop.  Callers place their own counted waits.
+// M0 (LDS destination base) is written in the same statement that uses it and restored.
+__device__ __forceinline__ void glds16_asm(const void *gsrc, float *lds_dst) {
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void glds4_asm(const void *gsrc, float *lds_dst) {
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 }  // namespace vi

@@ -36,7 +36,8 @@ class SearchStats(C.Structure):
     _fields_ = [("nq", u64), ("k", u64), ("n_probe_eff", u64), ("coarse_candidates", u64),
                 ("scanned_vectors", u64), ("scan_items", u64), ("ms_total", f32), ("ms_coarse", f32),
                 ("ms_group", f32), ("ms_scan", f32), ("ms_merge", f32), ("fallback_queries", u64),
-                ("filter_tile_blocks", u64), ("filter_rechecked", u64), ("filter_accepted", u64)]
+                ("filter_tile_blocks", u64), ("filter_rechecked", u64), ("filter_accepted", u64),
+                ("rank_mode", u64)]
 
 
 class AssignStats(C.Structure):
