@@ -231,10 +231,11 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
   }
 
 // one block image -> LDS: all of it, or (RANK 2) only its hi planes: pieces (chunk c, plane 0, half h) = 4c + h
-template <int NG, int RANK>
+template <int NG, int RANK, int NBUF>
 __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, const float *xn, int wave, int lane) {
   if constexpr (RANK != 2) {
-    tile_dma_image<NG>(tile, src, xn, wave, lane);
+    if constexpr (NBUF == 2) tile_dma_image_asm<NG>(tile, src, xn, wave, lane);  // the loop places its own waits
+    else tile_dma_image<NG>(tile, src, xn, wave, lane);
   } else {
 #pragma unroll
     for (int i0 = 0; i0 < NG; i0 += 4) {
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
   // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
   const uint32_t bi = (a.tile_start[l] + chunk * nblk) * 256u + 128u * (uint32_t)h + jq_grp;
 
-  tile_dma_rank<NG, RANK>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+  tile_dma_rank<NG, RANK, NBUF>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
     if (NBUF == 2 && more)
-      tile_dma_rank<NG, RANK>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+      tile_dma_rank<NG, RANK, NBUF>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                    a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
     if (NBUF == 1) {
       __syncthreads();  // every wave is done reading the tile
       if (more)
-        tile_dma_rank<NG, RANK>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+        tile_dma_rank<NG, RANK, NBUF>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                      a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // next tile visible
@@ -953,7 +954,8 @@ vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, h
     else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2>), grid, block, 0, st, a);
   } else if (rank_mode == 1) {
     if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
+    else if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 1>), grid, block, 0, st, a);
   } else if (table) {
     hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0>), grid, block, 0, st, a);
   } else if (nbuf == 1) {

@@ -60,4 +60,15 @@ __device__ __forceinline__ void glds4_asm(const void *gsrc, float *lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// tile_dma_image with the asm copies (double-buffered loops)
+template <int NG>
+__device__ __forceinline__ void tile_dma_image_asm(float *tile, const float4 *src, const float *xn, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < NG / 2; ++i) {
+    const int piece = wave + 4 * i;
+    glds16_asm(src + piece * 64 + lane, tile + piece * 256);
+  }
+  if (wave == 0) glds4_asm(xn + lane, tile + 2 * NG * 256);
+}
+
 }  // namespace vi
