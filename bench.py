@@ -275,7 +275,9 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_scan_traffic.json")) as f:
             tr = json.load(f)
-        same_kernel = ("filter_kernel" in tr["kernel"]) == (st["filter_tile_blocks"] > 0)
+        import re
+        m = re.search(r"filter_kernel<\d+, \d+, false, (\d+)>", tr["kernel"])
+        same_kernel = (int(m.group(1)) + 1 == int(st["rank_mode"])) if m else (st["filter_tile_blocks"] == 0)
         if tr["workload"] == [args.n, args.d, args.nlist, chosen, nq, k] and world == 1 and same_kernel:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
