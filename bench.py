@@ -170,10 +170,32 @@ def main():
         Dm = torch.empty((nq, k), dtype=torch.float32, device=device)
         Im = torch.empty((nq, k), dtype=torch.int64, device=device)
 
+    if world > 1:  # coarse step split over the ranks by query: each rank probes its slice, one all-gather of the probes
+        per = (nq + world - 1) // world
+        q0, q1 = min(nq, rank * per), min(nq, (rank + 1) * per)
+        pmax = 64
+        PR = torch.full((per, 2 * pmax), -1, dtype=torch.int32, device=device)       # [probes | order] of my slice
+        PRg = torch.empty((world * per, 2 * pmax), dtype=torch.int32, device=device)
+        probes_all = torch.empty((world * per, pmax), dtype=torch.int32, device=device)
+        order_all = torch.empty((world * per, pmax), dtype=torch.int32, device=device)
+
     def step(n_probe):
-        index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), T.data_ptr())
         if world == 1:
+            index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), T.data_ptr())
             return I
+        p_eff = min(n_probe, index.num_centroids)
+        pr = torch.empty((per, p_eff), dtype=torch.int32, device=device)
+        od = torch.empty((per, p_eff), dtype=torch.int32, device=device)
+        if q1 > q0:
+            index.probe_device(xq[q0:].data_ptr(), q1 - q0, n_probe, pr.data_ptr(), od.data_ptr())
+        PR[:, :p_eff] = pr
+        PR[:, pmax:pmax + p_eff] = od
+        dist.all_gather_into_tensor(PRg, PR)
+        pa = PRg[:nq, :p_eff].contiguous()
+        oa = PRg[:nq, pmax:pmax + p_eff].contiguous()
+        torch.cuda.synchronize()
+        index.search_probed_device(xq.data_ptr(), nq, k, p_eff, pa.data_ptr(), oa.data_ptr(), D.data_ptr(), I.data_ptr(),
+                                   T.data_ptr())
         dist.all_gather_into_tensor(Dg, D)
         dist.all_gather_into_tensor(Ig, I)
         dist.all_gather_into_tensor(Tg, T)

@@ -192,6 +192,23 @@ vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_de
                                    uint64_t k, uint64_t n_probe, float *D_dev, int64_t *I_dev,
                                    uint64_t *tie_dev);
 
+/* Multi-GPU: the two halves of vi_indexer_search_device as separate calls, so that the coarse step — identical on
+ * every rank, since the centroid table is replicated — can be SPLIT over the ranks by query instead of repeated:
+ *   vi_indexer_probe_device          ivf_index.rs:205-220 for a slice of the batch: the n_probe_eff = min(n_probe,
+ *                                    #centroids) nearest lists of each query in (distance, centroid index) order,
+ *                                    and order[q][r] = rank of probe r in the reference's candidate order (shard
+ *                                    visiting order, ivf_index.rs:223-262) — what the tie keys are built from;
+ *   (all-gather of probes / order over the ranks)
+ *   vi_indexer_search_probed_device  ivf_index.rs:223-274 for the whole batch against this rank's stripes with the
+ *                                    given probe lists; outputs as vi_indexer_search_device.
+ * Both return with their outputs complete; all pointers are device pointers; k and n_probe <= 64. */
+vi_status vi_indexer_probe_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t n_probe,
+                                  uint32_t *probes_dev, uint32_t *order_dev, uint64_t *n_probe_eff);
+vi_status vi_indexer_search_probed_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t k,
+                                          uint64_t n_probe_eff, const uint32_t *probes_dev,
+                                          const uint32_t *order_dev, float *D_dev, int64_t *I_dev,
+                                          uint64_t *tie_dev);
+
 /* Merge `parts` per-rank partial results (each nq x k, device pointers laid out
  * [part][nq][k]) into the global top-k with the reference's stable order. */
 vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts,

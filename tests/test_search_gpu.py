@@ -333,5 +333,22 @@ def test_striped_ranks_merge_to_the_single_gpu_result(world, tmp_path, monkeypat
                 assert rc == O.ORC_OK
                 assert (hip.download(Im, (nq, k), np.int64) == Io).all(), (engine, k, n_probe)
                 assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), (engine, k, n_probe)
+                # the same with the coarse step SPLIT over the ranks by query (vi_indexer_probe_device on a slice,
+                # "all-gather" = slices written side by side, vi_indexer_search_probed_device on every rank)
+                p_eff = min(n_probe, full.num_centroids)
+                probes, order = hip.alloc(nq * p_eff * 4), hip.alloc(nq * p_eff * 4)
+                per = (nq + world - 1) // world
+                for r, p in enumerate(parts):
+                    q0, q1 = min(nq, r * per), min(nq, (r + 1) * per)
+                    if q1 > q0:
+                        got = p.probe_device(xq + q0 * Q.shape[1] * 4, q1 - q0, n_probe, probes + q0 * p_eff * 4,
+                                             order + q0 * p_eff * 4)
+                        assert got == p_eff
+                for r, p in enumerate(parts):
+                    p.search_probed_device(xq, nq, k, p_eff, probes, order, Dg + r * nq * k * 4, Ig + r * nq * k * 8,
+                                           Tg + r * nq * k * 8)
+                _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+                assert (hip.download(Im, (nq, k), np.int64) == Io).all(), ("split coarse", engine, k, n_probe)
+                assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), ("split coarse", engine, k, n_probe)
     finally:
         hip.close()

@@ -323,6 +323,41 @@ vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_de
   return vi::device_index_search(*ix->impl.dev, io);
 }
 
+vi_status vi_indexer_probe_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t n_probe,
+                                  uint32_t *probes_dev, uint32_t *order_dev, uint64_t *n_probe_eff) {
+  uint64_t k = 1;
+  VI_TRY(search_common(ix, &k, &n_probe));
+  if (n_probe == 0) return fail(VI_ERR_INVALID_INPUT, "k and n_probe must be greater than 0");
+  if (!ix->impl.dev) return fail(VI_ERR_DEVICE, "index is not resident on a GPU (build or load it first)");
+  const uint64_t p_eff = std::min<uint64_t>(n_probe, ix->impl.meta.k());
+  if (n_probe_eff) *n_probe_eff = p_eff;
+  if (nq == 0 || p_eff == 0) return VI_OK;
+  if (!queries_dev || !probes_dev || !order_dev) return fail(VI_ERR_INVALID_INPUT, "null pointer");
+  vi::SearchIO io;
+  io.queries = queries_dev; io.on_device = true; io.nq = nq; io.k = 1; io.n_probe = n_probe;
+  io.probes_out = probes_dev; io.order_out = order_dev;
+  return vi::device_index_search(*ix->impl.dev, io);
+}
+
+vi_status vi_indexer_search_probed_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t k,
+                                          uint64_t n_probe_eff, const uint32_t *probes_dev,
+                                          const uint32_t *order_dev, float *D_dev, int64_t *I_dev,
+                                          uint64_t *tie_dev) {
+  uint64_t n_probe = n_probe_eff;
+  VI_TRY(search_common(ix, &k, &n_probe));
+  if (k == 0 || n_probe == 0) return fail(VI_ERR_INVALID_INPUT, "k and n_probe must be greater than 0");
+  if (nq == 0) return VI_OK;
+  if (!queries_dev || !D_dev || !I_dev || !probes_dev || !order_dev) return fail(VI_ERR_INVALID_INPUT, "null pointer");
+  if (!ix->impl.dev) return fail(VI_ERR_DEVICE, "index is not resident on a GPU (build or load it first)");
+  if (n_probe_eff != std::min<uint64_t>(n_probe, ix->impl.meta.k()))
+    return fail(VI_ERR_INVALID_INPUT, "n_probe_eff does not match this index (use the value vi_indexer_probe_device returned)");
+  vi::SearchIO io;
+  io.queries = queries_dev; io.on_device = true; io.nq = nq; io.k = k; io.n_probe = n_probe;
+  io.D = D_dev; io.I = I_dev; io.tie = tie_dev;
+  io.probes_in = probes_dev; io.order_in = order_dev;
+  return vi::device_index_search(*ix->impl.dev, io);
+}
+
 vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts, const float *D_parts,
                                    const int64_t *I_parts, const uint64_t *tie_parts, float *D_out, int64_t *I_out) {
   return vi::merge_partials_device(device, nq, k, parts, D_parts, I_parts, tie_parts, D_out, I_out);

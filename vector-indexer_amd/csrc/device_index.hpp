@@ -114,6 +114,9 @@ struct SearchIO {
   uint64_t *tie = nullptr;
   float *V = nullptr;              // host only
   uint64_t *counts = nullptr;      // host only
+  // multi-GPU: the coarse step of a query slice can run on another rank (device pointers, [nq][n_probe_eff])
+  const uint32_t *probes_in = nullptr, *order_in = nullptr;  // skip the coarse step, use these probe lists
+  uint32_t *probes_out = nullptr, *order_out = nullptr;      // coarse step only: probe lists + candidate-order ranks
 };
 vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io);
 // squared norms of the stored vectors (filter_search.hip); called at the end of every index upload

@@ -56,6 +56,8 @@ namespace vi {
 
 // provided by search_kernels.hip
 vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
+vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
+                       bool histogram, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[6], hipStream_t st, bool histogram_done);
 
@@ -1165,16 +1167,29 @@ bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint
   return true;
 }
 
+// the list-phase segment size (VI_FILTER_SEGB)
+static uint32_t list_segb0() {
+  const char *sb = getenv("VI_FILTER_SEGB");
+  return sb ? (uint32_t)std::max(1, atoi(sb)) : 32u;  // <= 2048 vectors per work item
+}
+
+// coarse step alone on the matrix cores (probe export for other ranks): fills ws.probes / ws.gorder
+vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
+  SearchWorkspace &ws = ix.ws;
+  VI_TRY(ws.pair_rel.reserve(nq * P));
+  VI_TRY(ws.qtot.reserve(nq));
+  return stage_coarse_filter(ix, Qd, nq, P, list_segb0(), st);
+}
+
 vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                  float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                                 bool timing) {
+                                 bool timing, const uint32_t *probes_in, const uint32_t *order_in) {
   SearchWorkspace &ws = ix.ws;
   vi_search_stats &stt = ix.stats;
   const uint32_t dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   (void)K;
-  const char *sb = getenv("VI_FILTER_SEGB");
-  const uint32_t segb0 = sb ? (uint32_t)std::max(1, atoi(sb)) : 32u;  // <= 2048 vectors per work item
+  const uint32_t segb0 = list_segb0();
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
@@ -1184,10 +1199,11 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
     const char *cf = getenv("VI_COARSE_FILTER");
-    if (!(cf && *cf == '0') && nq >= 256 && nlists >= 1024) {
+    if (!probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024) {
       VI_TRY(stage_coarse_filter(ix, Qd, nq, P, segb0, st));
     } else {
-      VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+      if (probes_in) VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, true, st));
+      else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
       hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
                          ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p);
     }

@@ -962,7 +962,8 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
 
 vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                  float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                                 bool timing);
+                                 bool timing, const uint32_t *probes_in, const uint32_t *order_in);
+vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
 bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint32_t P);
 
 vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
@@ -1004,9 +1005,30 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
 }
 
 // exact-order VALU pipeline: coarse -> group -> list scan -> final merge
+// probes given by the caller (multi-GPU: coarse step done elsewhere): probe lists + candidate-order ranks into
+// the workspace, and the per-list histogram the grouping scan starts from
+vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
+                       bool histogram, hipStream_t st) {
+  SearchWorkspace &ws = ix.ws;
+  const uint64_t nlists = ix.nlists;
+  VI_TRY(ws.probes.reserve(nq * P));
+  VI_TRY(ws.gorder.reserve(nq * P));
+  VI_HIP(hipMemcpyAsync(ws.probes.p, probes_in, nq * P * 4, hipMemcpyDeviceToDevice, st));
+  VI_HIP(hipMemcpyAsync(ws.gorder.p, order_in, nq * P * 4, hipMemcpyDeviceToDevice, st));
+  if (histogram) {
+    const uint32_t total = (uint32_t)(nq * P);
+    VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
+    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p, ix.list_len.p, total, P,
+                       ws.cnt.p);
+    VI_HIP(hipGetLastError());
+  }
+  return VI_OK;
+}
+
 vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                               bool timing) {
+                               bool timing, const uint32_t *probes_in, const uint32_t *order_in) {
   SearchWorkspace &ws = ix.ws;
   vi_search_stats &stt = ix.stats;
   const uint32_t dim = ix.dim, dq = ix.dq;
@@ -1017,7 +1039,8 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
 
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
-  VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+  if (probes_in) VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, true, st));
+  else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
   // ---- 3. group (query,probe) pairs by list ----
   const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
@@ -1153,12 +1176,22 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 
   const bool use_filter = !generic && filter_path_applicable(ix, nq, k, P);
   const bool timing = ix.timing && !generic;
+  if (io.probes_out) {  // coarse step only (multi-GPU: this rank's slice of the queries)
+    if (P > kMaxSelect) return fail(VI_ERR_INVALID_INPUT, "probe export supports n_probe <= 64");
+    if (filter_path_applicable(ix, nq, 1, P) && nq >= 256 && nlists >= 1024) VI_TRY(coarse_only_filter(ix, Qd, nq, P, st));
+    else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
+    VI_HIP(hipMemcpyAsync(io.probes_out, ws.probes.p, nq * P * 4, hipMemcpyDeviceToDevice, st));
+    VI_HIP(hipMemcpyAsync(io.order_out, ws.gorder.p, nq * P * 4, hipMemcpyDeviceToDevice, st));
+    VI_HIP(hipStreamSynchronize(st));
+    return VI_OK;
+  }
+  if (io.probes_in && generic) return fail(VI_ERR_INVALID_INPUT, "given probes support k and n_probe <= 64");
   if (generic) {
     VI_TRY(device_index_search_generic(ix, Qd, nq, k, P, Dd, Id, Td, slots, ws.counts.p, st));
   } else if (use_filter) {
-    VI_TRY(search_filter_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing));
+    VI_TRY(search_filter_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing, io.probes_in, io.order_in));
   } else {
-    VI_TRY(search_valu_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing));
+    VI_TRY(search_valu_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing, io.probes_in, io.order_in));
   }
 
   if (ix.stripe_world > 1 && Td) {

@@ -113,6 +113,22 @@ class VectorIndex:
                                                      C.c_void_p(I_ptr), C.c_void_p(tie_ptr) if tie_ptr else None))
 
 
+    def probe_device(self, xq_ptr: int, nq: int, n_probe: int, probes_ptr: int, order_ptr: int) -> int:
+        """coarse step only (ivf_index.rs:205-220) -> n_probe_eff; probes / order are u32[nq][n_probe_eff] on the device"""
+        p_eff = C.c_uint64(0)
+        _native.check(lib().vi_indexer_probe_device(self._h, C.c_void_p(xq_ptr), nq, n_probe, C.c_void_p(probes_ptr),
+                                                    C.c_void_p(order_ptr), C.byref(p_eff)))
+        return int(p_eff.value)
+
+    def search_probed_device(self, xq_ptr: int, nq: int, k: int, n_probe_eff: int, probes_ptr: int, order_ptr: int,
+                             D_ptr: int, I_ptr: int, tie_ptr: int = 0):
+        """list scan + top-k (ivf_index.rs:223-274) with probe lists computed elsewhere"""
+        _native.check(lib().vi_indexer_search_probed_device(self._h, C.c_void_p(xq_ptr), nq, k, n_probe_eff,
+                                                            C.c_void_p(probes_ptr), C.c_void_p(order_ptr),
+                                                            C.c_void_p(D_ptr), C.c_void_p(I_ptr),
+                                                            C.c_void_p(tie_ptr) if tie_ptr else None))
+
+
 def _config(dimension, index_dir, shards_dir, **ext):
     cfg = _native.Config()
     lib().vi_config_init(C.byref(cfg), int(dimension))

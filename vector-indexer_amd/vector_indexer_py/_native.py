@@ -66,6 +66,8 @@ SIGNATURES = {
     "vi_indexer_build_from_vector_file": (C.c_int, [vp, C.c_char_p]),
     "vi_indexer_search": (C.c_int, [vp, vp, u64, u32, u64, u64, vp, vp, vp, vp, C.POINTER(u64)]),
     "vi_indexer_search_device": (C.c_int, [vp, vp, u64, u64, u64, vp, vp, vp]),
+    "vi_indexer_probe_device": (C.c_int, [vp, vp, u64, u64, vp, vp, C.POINTER(u64)]),
+    "vi_indexer_search_probed_device": (C.c_int, [vp, vp, u64, u64, u64, vp, vp, vp, vp, vp]),
     "vi_merge_partials_device": (C.c_int, [i32, u64, u64, u32, vp, vp, vp, vp, vp]),
     "vi_indexer_dimension": (u32, [vp]),
     "vi_indexer_num_centroids": (u64, [vp]),
