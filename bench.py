@@ -12,7 +12,8 @@ of NQ queries that are already resident in HBM.  value = queries/s over the time
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same index is partitioned by
 block over the ranks (block b of every list on rank b % N), every rank searches the full query batch against the
-lists it owns, the per-rank top-k are exchanged with ONE all-gather over RCCL and merged with the
+lists it owns, the per-rank top-k are exchanged with ONE all-gather over RCCL (after one all-gather of the probe
+lists: the coarse step is split over the ranks by query) and merged with the
 reference's stable candidate order.  Total work is fixed => "scaling": "strong".
 
 Prints ONE JSON line (rank 0).
@@ -164,9 +165,12 @@ def main():
     I = torch.empty((nq, k), dtype=torch.int64, device=device)
     T = torch.empty((nq, k), dtype=torch.int64, device=device)
     if world > 1:
-        Dg = torch.empty((world * nq, k), dtype=torch.float32, device=device)
-        Ig = torch.empty((world * nq, k), dtype=torch.int64, device=device)
-        Tg = torch.empty((world * nq, k), dtype=torch.int64, device=device)
+        # per-rank results packed [D | I | tie] so that ONE all-gather exchanges them
+        S = int(_native.lib().vi_packed_result_bytes(nq, k))
+        off_i = (nq * k * 4 + 7) // 8 * 8
+        off_t = off_i + nq * k * 8
+        mine = torch.empty(S, dtype=torch.uint8, device=device)
+        gathered = torch.empty(world * S, dtype=torch.uint8, device=device)
         Dm = torch.empty((nq, k), dtype=torch.float32, device=device)
         Im = torch.empty((nq, k), dtype=torch.int64, device=device)
 
@@ -194,14 +198,13 @@ def main():
         pa = PRg[:nq, :p_eff].contiguous()
         oa = PRg[:nq, pmax:pmax + p_eff].contiguous()
         torch.cuda.synchronize()
-        index.search_probed_device(xq.data_ptr(), nq, k, p_eff, pa.data_ptr(), oa.data_ptr(), D.data_ptr(), I.data_ptr(),
-                                   T.data_ptr())
-        dist.all_gather_into_tensor(Dg, D)
-        dist.all_gather_into_tensor(Ig, I)
-        dist.all_gather_into_tensor(Tg, T)
+        base = mine.data_ptr()
+        index.search_probed_device(xq.data_ptr(), nq, k, p_eff, pa.data_ptr(), oa.data_ptr(), base, base + off_i,
+                                   base + off_t)
+        dist.all_gather_into_tensor(gathered, mine)
         torch.cuda.synchronize()
-        _native.check(_native.lib().vi_merge_partials_device(local_rank, nq, k, world, Dg.data_ptr(), Ig.data_ptr(),
-                                                             Tg.data_ptr(), Dm.data_ptr(), Im.data_ptr()))
+        _native.check(_native.lib().vi_merge_partials_packed_device(local_rank, nq, k, world, gathered.data_ptr(),
+                                                                    Dm.data_ptr(), Im.data_ptr()))
         return Im
 
     # ---- operating point: nprobe sweep against exact ground truth -----------------------------

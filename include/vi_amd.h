@@ -215,6 +215,13 @@ vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint
                                    const float *D_parts, const int64_t *I_parts,
                                    const uint64_t *tie_parts, float *D_out, int64_t *I_out);
 
+/* The same merge for results PACKED per rank as [D f32 nq*k | pad to 8 B | I i64 nq*k | tie u64 nq*k]
+ * (vi_packed_result_bytes(nq, k) bytes; point vi_indexer_search*_device's D / I / tie outputs into one such buffer):
+ * the ranks then exchange their partial results with ONE all-gather instead of three. */
+uint64_t vi_packed_result_bytes(uint64_t nq, uint64_t k);
+vi_status vi_merge_partials_packed_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts,
+                                          const void *packed_dev, float *D_out, int64_t *I_out);
+
 /* accessors */
 uint32_t vi_indexer_dimension(const vi_indexer *ix);
 uint64_t vi_indexer_num_centroids(const vi_indexer *ix);

@@ -350,5 +350,15 @@ def test_striped_ranks_merge_to_the_single_gpu_result(world, tmp_path, monkeypat
                 _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
                 assert (hip.download(Im, (nq, k), np.int64) == Io).all(), ("split coarse", engine, k, n_probe)
                 assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), ("split coarse", engine, k, n_probe)
+                # and with every rank's results packed [D | I | tie] (ONE all-gather): the strided merge
+                S = int(_native.lib().vi_packed_result_bytes(nq, k))
+                off_i = (nq * k * 4 + 7) // 8 * 8
+                packed = hip.alloc(world * S)
+                for r, p in enumerate(parts):
+                    b = packed + r * S
+                    p.search_probed_device(xq, nq, k, p_eff, probes, order, b, b + off_i, b + off_i + nq * k * 8)
+                _native.check(_native.lib().vi_merge_partials_packed_device(0, nq, k, world, packed, Dm, Im))
+                assert (hip.download(Im, (nq, k), np.int64) == Io).all(), ("packed", engine, k, n_probe)
+                assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), ("packed", engine, k, n_probe)
     finally:
         hip.close()

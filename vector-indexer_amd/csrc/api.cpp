@@ -363,6 +363,13 @@ vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint
   return vi::merge_partials_device(device, nq, k, parts, D_parts, I_parts, tie_parts, D_out, I_out);
 }
 
+vi_status vi_merge_partials_packed_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts, const void *packed_dev,
+                                          float *D_out, int64_t *I_out) {
+  return vi::merge_partials_packed_device(device, nq, k, parts, packed_dev, D_out, I_out);
+}
+
+uint64_t vi_packed_result_bytes(uint64_t nq, uint64_t k) { return (nq * k * 4 + 7) / 8 * 8 + 2 * nq * k * 8; }
+
 uint32_t vi_indexer_dimension(const vi_indexer *ix) { return ix ? ix->impl.meta.dimension : 0; }
 uint64_t vi_indexer_num_centroids(const vi_indexer *ix) { return ix ? ix->impl.meta.k() : 0; }
 uint64_t vi_indexer_num_vectors(const vi_indexer *ix) { return ix && ix->impl.dev ? ix->impl.dev->nvec_resident : 0; }

@@ -133,6 +133,8 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
                                  const std::vector<uint32_t> &member_rows, const uint64_t *ids_dev,
                                  const std::vector<uint32_t> *list_shard, DeviceIndex *out);
 
+vi_status merge_partials_packed_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const void *packed,
+                                       float *D_out, int64_t *I_out);
 vi_status merge_partials_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const float *D_parts,
                                 const int64_t *I_parts, const uint64_t *tie_parts, float *D_out,
                                 int64_t *I_out);

@@ -533,14 +533,19 @@ __global__ void __launch_bounds__(kBlockThreads) final_merge_kernel(FinalMergeAr
 }
 
 // merge `parts` partial top-k lists per query (multi-GPU): key = (dist, tie)
+// part p of Dp / Ip / Tp starts p * stride elements (of the respective type) after part 0
 __global__ void __launch_bounds__(kBlockThreads) merge_partials_kernel(uint64_t nq, uint32_t k, uint32_t parts,
-                                                                      const float *Dp, const int64_t *Ip,
-                                                                      const uint64_t *Tp, float *D, int64_t *I) {
+                                                                      const float *Dp0, const int64_t *Ip0,
+                                                                      const uint64_t *Tp0, size_t strideD,
+                                                                      size_t strideI, float *D, int64_t *I) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint64_t q = (uint64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (q >= nq) return;
   // lane = part (parts <= 64); each part's list is sorted by (dist, tie) already
-  const size_t base = ((size_t)lane * nq + q) * k;
+  const float *Dp = Dp0 + (size_t)(lane < (int)parts ? lane : 0) * strideD;
+  const int64_t *Ip = Ip0 + (size_t)(lane < (int)parts ? lane : 0) * strideI;
+  const uint64_t *Tp = Tp0 + (size_t)(lane < (int)parts ? lane : 0) * strideI;
+  const size_t base = (size_t)q * k;
   uint32_t head = 0;
   bool live = lane < (int)parts;
   float hd = INFINITY;
@@ -1269,7 +1274,26 @@ vi_status merge_partials_device(int device, uint64_t nq, uint64_t k, uint32_t pa
   if (nq == 0 || k == 0) return VI_OK;
   VI_HIP(hipSetDevice(device));
   hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
-                     dim3(kBlockThreads), 0, 0, nq, (uint32_t)k, parts, D_parts, I_parts, tie_parts, D_out, I_out);
+                     dim3(kBlockThreads), 0, 0, nq, (uint32_t)k, parts, D_parts, I_parts, tie_parts, (size_t)(nq * k),
+                     (size_t)(nq * k), D_out, I_out);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipStreamSynchronize(0));
+  return VI_OK;
+}
+
+// parts packed one after the other, each [D f32 nq*k | pad to 8 B | I i64 nq*k | tie u64 nq*k]: what ONE all-gather of a
+// rank's packed results produces
+vi_status merge_partials_packed_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const void *packed,
+                                       float *D_out, int64_t *I_out) {
+  if (parts == 0 || parts > kWave) return fail(VI_ERR_INVALID_INPUT, "parts must be 1..64");
+  if (nq == 0 || k == 0) return VI_OK;
+  VI_HIP(hipSetDevice(device));
+  const size_t offI = (nq * k * 4 + 7) / 8 * 8, offT = offI + nq * k * 8, stride = offT + nq * k * 8;
+  const uint8_t *b = static_cast<const uint8_t *>(packed);
+  hipLaunchKernelGGL(merge_partials_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
+                     dim3(kBlockThreads), 0, 0, nq, (uint32_t)k, parts, reinterpret_cast<const float *>(b),
+                     reinterpret_cast<const int64_t *>(b + offI), reinterpret_cast<const uint64_t *>(b + offT),
+                     stride / 4, stride / 8, D_out, I_out);
   VI_HIP(hipGetLastError());
   VI_HIP(hipStreamSynchronize(0));
   return VI_OK;

@@ -69,6 +69,8 @@ SIGNATURES = {
     "vi_indexer_probe_device": (C.c_int, [vp, vp, u64, u64, vp, vp, C.POINTER(u64)]),
     "vi_indexer_search_probed_device": (C.c_int, [vp, vp, u64, u64, u64, vp, vp, vp, vp, vp]),
     "vi_merge_partials_device": (C.c_int, [i32, u64, u64, u32, vp, vp, vp, vp, vp]),
+    "vi_packed_result_bytes": (u64, [u64, u64]),
+    "vi_merge_partials_packed_device": (C.c_int, [i32, u64, u64, u32, vp, vp, vp]),
     "vi_indexer_dimension": (u32, [vp]),
     "vi_indexer_num_centroids": (u64, [vp]),
     "vi_indexer_num_vectors": (u64, [vp]),
