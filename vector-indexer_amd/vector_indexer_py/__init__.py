@@ -43,8 +43,11 @@ class VectorIndex:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
-            lib().vi_indexer_free(h)
+        if h and lib is not None:  # (module globals are already torn down at interpreter exit)
+            try:
+                lib().vi_indexer_free(h)
+            except Exception:
+                pass
 
     @property
     def dimension(self) -> int:
