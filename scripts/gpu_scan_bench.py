@@ -47,5 +47,7 @@ def run(label, n_probe, reps=6, **env):
 
 for p in (16,):
     run("default", p)
-    run("bf16x3 (lo planes streamed)", p, VI_FILTER_HI_ONLY=0)
-    run("f32 mfma", p, VI_FILTER_BF16=0)
+    run("no epilogue", p, VI_FILTER_XMODE=2)
+    run("no brec store", p, VI_FILTER_XMODE=8)
+    run("segb 16", p, VI_FILTER_SEGB=16)
+    run("segb 64", p, VI_FILTER_SEGB=64)
