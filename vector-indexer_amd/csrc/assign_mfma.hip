@@ -279,9 +279,11 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_bf16_kernel(MfmaArgs a) {
   for (uint32_t ct = 0; ct < ntiles; ++ct) {
     const float *cur = lds + (ct & 1) * kImgFloats;
     // next tile lands in the other buffer during this tile's MFMAs (everyone left it at the last barrier)
+    // (inline-asm copies: with the builtin hipcc waits vmcnt(0) before the first ds_read below — it cannot tell the two
+    // buffers apart — and the load would not overlap the MFMAs)
     if (ct + 1 < ntiles)
-      tile_dma_image<NG>(lds + ((ct + 1) & 1) * kImgFloats, a.img + (ct + 1) * img_stride, a.cn + (size_t)(ct + 1) * kTileC,
-                         wave, lane);
+      tile_dma_image_asm<NG>(lds + ((ct + 1) & 1) * kImgFloats, a.img + (ct + 1) * img_stride,
+                             a.cn + (size_t)(ct + 1) * kTileC, wave, lane);
     f32x16 acc0, acc1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // rows 8q + 4h + (0..3) live in regs 4q .. 4q+3
