@@ -362,3 +362,33 @@ def test_striped_ranks_merge_to_the_single_gpu_result(world, tmp_path, monkeypat
                 assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), ("packed", engine, k, n_probe)
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VI_FUZZ_SEEDS", "12"))))
+def test_randomized_shapes_parity(seed, tmp_path):
+    """random shape / data / request per seed (dims, list counts, ties, scale, k, n_probe, batch size) against the
+    oracle — under every ranking arithmetic (the _engine fixture)."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 96, 100, 128, 5, 130]))
+    n = int(rng.integers(300, 6000))
+    nlist = int(rng.integers(1, 60))
+    kind = rng.choice(["gauss", "ints", "dups", "scaled", "offset"])
+    if kind == "gauss":
+        X = rng.standard_normal((n, d))
+    elif kind == "ints":
+        X = rng.integers(0, 256, size=(n, d))
+    elif kind == "dups":
+        X = rng.integers(-2, 3, size=(max(n // 8, 8), d))[rng.integers(0, max(n // 8, 8), size=n)]
+    elif kind == "scaled":
+        X = rng.standard_normal((n, d)) * np.exp(rng.uniform(-6, 6, size=(1, d)))
+    else:
+        X = 300.0 + rng.standard_normal((n, d))
+    X = X.astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    nq = int(rng.choice([1, 3, 64, 200, 500]))
+    Q = np.concatenate([X[rng.integers(0, n, size=nq // 2 + 1)],
+                        (X[rng.integers(0, n, size=nq)] * (1 + 0.05 * rng.standard_normal((nq, d)))).astype(np.float32)])[:max(nq, 1)]
+    for _ in range(3):
+        k = int(rng.choice([1, 2, 10, 33, 64]))
+        n_probe = int(rng.choice([1, 2, 7, 16, 40, 64]))
+        check_parity(orc, gpu, Q, k, n_probe)
