@@ -948,22 +948,17 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
 template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, hipStream_t st) {
   if (nitems == 0) return VI_OK;
-  static const int nbuf = [] { const char *e = getenv("VI_FILTER_NBUF"); return e ? atoi(e) : 1; }();
   const bool table = a.qoff == nullptr;
   const dim3 grid(nitems), block(256);
   if (rank_mode == 2) {  // half-size tiles: two buffers fit where one full image did, the next tile loads during the MFMAs
     if (table) hipLaunchKernelGGL((filter_kernel<NG, 2, true, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2>), grid, block, 0, st, a);
-  } else if (rank_mode == 1) {
+  } else if (rank_mode == 1) {  // full images: one buffer, three workgroups per CU (two buffers cost the third: measured slower)
     if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1>), grid, block, 0, st, a);
-    else if (nbuf == 1) hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 1>), grid, block, 0, st, a);
-  } else if (table) {
-    hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0>), grid, block, 0, st, a);
-  } else if (nbuf == 1) {
-    hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
   } else {
-    hipLaunchKernelGGL((filter_kernel<NG, 2, false, 0>), grid, block, 0, st, a);
+    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0>), grid, block, 0, st, a);
   }
   VI_HIP(hipGetLastError());
   return VI_OK;
