@@ -90,9 +90,10 @@ vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint
 typedef struct vi_assign_stats {
   uint64_t n, k;
   uint64_t ambiguous_rows; /* rows re-evaluated exactly (VI_ASSIGN_EXACT / brute-force path) */
-  uint32_t used_mfma;      /* 1 when the f32-MFMA filter ran, 0 for the exact-order scan kernel */
+  uint32_t used_mfma;      /* 1 when the MFMA tiers ran (bf16 x 3, then f32 on the rows that one leaves ambiguous),
+                              0 for the exact-order scan kernel alone */
   float ms_total;          /* wall time of the call incl. the exact re-check */
-  float ms_filter;         /* HIP-event time of the MFMA kernel alone */
+  float ms_filter;         /* HIP-event time of the first-tier MFMA kernel alone */
 } vi_assign_stats;
 vi_status vi_assign_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, const float *C_dev,
                            uint64_t k, uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev,
