@@ -284,9 +284,10 @@ def main():
         flops = 2.0 * args.d * st["scanned_vectors"]
         tf = flops / scan_s / 1e12 if scan_s > 0 else 0.0
         image = 64 * dq * (8 if mode == 3 else 16)       # bytes of one block image streamed per tile
-        tile_bytes = tiles * (image + 256 * 16)           # + 2 x 128 block records of 16 B per tile
+        gq = int(st["group_queries"]) or 128
+        tile_bytes = tiles * (image + 2 * gq * 16)        # + 2 x gq block records of 16 B per tile
         stream = tile_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        extra = {"flops_per_launch": flops, "useful_TFLOPs": round(tf, 1), "tiles_per_launch": int(tiles),
+        extra = {"queries_per_work_item": gq, "flops_per_launch": flops, "useful_TFLOPs": round(tf, 1), "tiles_per_launch": int(tiles),
                  "tile_bytes_per_launch": int(tile_bytes), "tile_stream_GBps": round(stream, 1),
                  "survey_accounting_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common}
         if mode == 3:

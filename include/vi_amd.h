@@ -245,6 +245,7 @@ typedef struct vi_search_stats {
   uint64_t filter_accepted;    /* VI_FILTER_STATS=1: block records consulted */
   uint64_t rank_mode;          /* list scan of the last search: 0 exact-order VALU engine, 1 f32 MFMA,
                                   2 bf16 x 3 MFMA, 3 bf16 MFMA on hi planes only (bf16-exact stored values) */
+  uint64_t group_queries;      /* MFMA path: queries per rank work item (128, or 32 when lists are probed by few) */
 } vi_search_stats;
 /* stats of the most recent search on this handle (timing collected only if enabled) */
 vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out);

@@ -19,10 +19,11 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.fixture(params=["default-engine", "valu-engine", "mfma-f32", "mfma-bf16x3-always"], autouse=True)
+@pytest.fixture(params=["default-engine", "valu-engine", "mfma-f32", "mfma-bf16x3-always", "mfma-groups-of-128"],
+                autouse=True)
 def _engine(request, monkeypatch):
     """every test of this file runs with each ranking arithmetic: the library's own choice (MFMA path wherever it
-    applies: bf16 x 3, hi planes only on bf16-exact data), the exact-order VALU engine, the f32 MFMA, and bf16 x 3
+    applies: bf16 x 3, hi planes only on bf16-exact data, 32- or 128-query work items by batch density), the exact-order VALU engine, the f32 MFMA, and bf16 x 3
     with the lo planes always streamed; tests that set VI_FILTER themselves override only the engine choice"""
     if request.param == "valu-engine":
         monkeypatch.setenv("VI_FILTER", "0")
@@ -30,6 +31,8 @@ def _engine(request, monkeypatch):
         monkeypatch.setenv("VI_FILTER_BF16", "0")
     elif request.param == "mfma-bf16x3-always":
         monkeypatch.setenv("VI_FILTER_HI_ONLY", "0")
+    elif request.param == "mfma-groups-of-128":   # these small batches default to 32-query work items
+        monkeypatch.setenv("VI_FILTER_GQ", "128")
     yield
 
 

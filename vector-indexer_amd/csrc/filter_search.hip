@@ -233,14 +233,14 @@ __device__ __forceinline__ float pack_idx(float m, uint32_t e) {
   }
 
 // one block image -> LDS: all of it, or (RANK 2) only its hi planes: pieces (chunk c, plane 0, half h) = 4c + h
-template <int NG, int RANK, int NBUF>
+template <int NG, int RANK, int NBUF, int WAVES>
 __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, const float *xn, int wave, int lane) {
   if constexpr (RANK != 2) {
-    if constexpr (NBUF == 2) tile_dma_image_asm<NG>(tile, src, xn, wave, lane);  // the loop places its own waits
-    else tile_dma_image<NG>(tile, src, xn, wave, lane);
+    if constexpr (NBUF == 2) tile_dma_image_asm<NG, WAVES>(tile, src, xn, wave, lane);  // the loop places its own waits
+    else tile_dma_image<NG, WAVES>(tile, src, xn, wave, lane);
   } else {
 #pragma unroll
-    for (int i0 = 0; i0 < NG; i0 += 4) {
+    for (int i0 = 0; i0 < NG; i0 += WAVES) {
       const int i = i0 + wave;
       if (i < NG) {
         const int piece = 4 * (i >> 1) + (i & 1);  // hi piece i = 2c + h lands compactly at i
@@ -257,8 +257,13 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
 // RANK 2: the stored values are bf16-exact (every lo plane is zero: 8-bit descriptors such as SIFT) — only the hi
 // planes are staged (half the bytes) and lo.hi is dropped; hi.lo is dropped too for a wave whose 32 queries are
 // bf16-exact (wave-uniform test), which leaves ONE MFMA per 16 dims with the result still exact to f32 rounding.
-template <int NG, int NBUF, bool TABLE, int RANK>
-__global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_kernel(FilterArgs a) {
+// GQ = queries per work item: 128 (4 waves) when lists are probed by many queries of the batch, 32 (one wave per
+// workgroup, up to 9 workgroups per CU) when a list is probed by a handful — large balanced indexes, where a
+// 128-query group would leave three of its four waves idle behind the same tile stream.
+template <int NG, int NBUF, bool TABLE, int RANK, int GQ>
+__global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBUF == 1 || RANK == 2) ? 3 : 2))
+    filter_kernel(FilterArgs a) {  // (second bound = waves per SIMD the register allocation must allow)
+  constexpr int WAVES = GQ / 32;
   constexpr int kImage = (RANK == 2 ? NG : 2 * NG) * 256;  // floats of the staged image (RANK 2: hi planes only)
   constexpr int kTileFloats = kImage + 64;                 // + the block's 64 norms
   __shared__ __attribute__((aligned(16))) float s_tiles[NBUF][kTileFloats];
@@ -282,15 +287,15 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
   const uint32_t nseg = list_segments(len, a.segb0, &segb);
   const uint32_t local = item - a.item_start[l];
   const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
-  const uint32_t j0 = chunk * kGroupQ;
-  const uint32_t nqi = min((uint32_t)kGroupQ, cnt - j0);
+  const uint32_t j0 = chunk * GQ;
+  const uint32_t nqi = min((uint32_t)GQ, cnt - j0);
   const uint32_t fb = a.first_block[l];
   const uint32_t nblk = (len + kWave - 1) / kWave;
   const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
 
   // ---- this lane's query: both lane halves hold query j of the wave's tile ----
   // the tile a wave owns rotates with the item so that partially filled groups do not always idle the same SIMD
-  const uint32_t wtile = ((uint32_t)wave + item) & 3u;
+  const uint32_t wtile = ((uint32_t)wave + item) % (uint32_t)WAVES;
   const uint32_t jq_grp = 32u * wtile + (uint32_t)j;
   const bool qlive = jq_grp < nqi;
   const bool wave_live = 32u * wtile < nqi;  // wave-uniform
@@ -335,9 +340,9 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
   uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos;  // (T3 only guards: its position is never needed)
   // block records are item-major — [tile = (query group, block)][lane half][query of the group] — so that a
   // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
-  const uint32_t bi = (a.tile_start[l] + chunk * nblk) * 256u + 128u * (uint32_t)h + jq_grp;
+  const uint32_t bi = (a.tile_start[l] + chunk * nblk) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
 
-  tile_dma_rank<NG, RANK, NBUF>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+  tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
@@ -346,7 +351,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
     if (NBUF == 2 && more)
-      tile_dma_rank<NG, RANK, NBUF>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+      tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                    a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
           bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
           bm1 = fminf(bm1, p);
         }
-        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + 256u * blk] = make_float4(bm1, bm2, bm3, bm4);
+        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + (2u * GQ) * blk] = make_float4(bm1, bm2, bm3, bm4);
         // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
         const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
         if (!(a.xmode & 16u)) {
@@ -467,7 +472,7 @@ __global__ void __launch_bounds__(256, (NBUF == 1 || RANK == 2) ? 3 : 2) filter_
     if (NBUF == 1) {
       __syncthreads();  // every wave is done reading the tile
       if (more)
-        tile_dma_rank<NG, RANK, NBUF>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
+        tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                      a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // next tile visible
@@ -501,13 +506,14 @@ struct SelectCommon {
   const uint4 *gpos;
   const float4 *brec;
   float gamma, e_scale, xmax2;
+  uint32_t gq;  // queries per rank work item (block-record tiles hold 2 * gq records)
   unsigned long long *dbg;  // [6] exact re-evaluations, [7] block records consulted
 };
 
 // the query's probes, one per lane r < P
 struct ProbeRegs {
   uint32_t rel, ng;   // first group record (relative to the query's) / number of group records of the probe
-  uint32_t boff;      // block record of (block 0, lane half 0) of the probe; + 256 per block, + 128 for half 1
+  uint32_t boff;      // block record of (block 0, lane half 0) of the probe; + 2*gq per block, + gq for half 1
   uint32_t len, fb;   // list length and first block
   uint32_t segb;      // blocks per segment
   uint32_t g;         // candidate-order rank (shard visiting order)
@@ -642,7 +648,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       const uint32_t r = ck >> (kBlkBits + 1), blk = (ck >> 1) & ((1u << kBlkBits) - 1u), hh = ck & 1u;
       const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)r);
       float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-      if (live) B = c.brec[(size_t)boff + 256u * blk + 128u * hh];
+      if (live) B = c.brec[(size_t)boff + 2u * c.gq * blk + c.gq * hh];
       if (mode == 0) {
         s1 = offer_bulk_fn(s1, B.x, live ? 0u : kNoPos, (int)K);
         s1 = offer_bulk_fn(s1, B.y, live ? 1u : kNoPos, (int)K);
@@ -859,7 +865,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
       pr.len = a.list_len[mylist];
       pr.fb = a.first_block[mylist];
       const uint32_t pp = a.pair_pos[s];  // where the pair sits among the pairs of its list
-      pr.boff = (a.tile_start[mylist] + (pp / kGroupQ) * ((pr.len + 63u) / 64u)) * 256u + (pp % kGroupQ);
+      pr.boff = (a.tile_start[mylist] + (pp / a.c.gq) * ((pr.len + 63u) / 64u)) * (2u * a.c.gq) + (pp % a.c.gq);
       pr.ng = 2u * list_segments(pr.len, a.segb0, &pr.segb);
     }
   }
@@ -915,7 +921,7 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, 0u};
   if (lane == 0) {
     pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb;
-    pr.boff = (q / kGroupQ) * ((a.nlists + 63u) / 64u) * 256u + (q % kGroupQ);  // pairs = iota: the query's own position
+    pr.boff = (q / a.c.gq) * ((a.nlists + 63u) / 64u) * (2u * a.c.gq) + (q % a.c.gq);  // pairs = iota: the query's own position
   }
   WaveTopK sel;
   select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
@@ -946,34 +952,42 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
 }
 
 template <int NG>
-vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, hipStream_t st) {
+vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, uint32_t gq, hipStream_t st) {
   if (nitems == 0) return VI_OK;
   const bool table = a.qoff == nullptr;
-  const dim3 grid(nitems), block(256);
-  if (rank_mode == 2) {  // half-size tiles: two buffers fit where one full image did, the next tile loads during the MFMAs
-    if (table) hipLaunchKernelGGL((filter_kernel<NG, 2, true, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2>), grid, block, 0, st, a);
-  } else if (rank_mode == 1) {  // full images: one buffer, three workgroups per CU (two buffers cost the third: measured slower)
-    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1>), grid, block, 0, st, a);
+  const dim3 grid(nitems);
+  if (gq == 32) {  // one wave per work item (lists only): single buffer, many workgroups per CU
+    const dim3 block(64);
+    if (rank_mode == 2) hipLaunchKernelGGL((filter_kernel<NG, 1, false, 2, 32>), grid, block, 0, st, a);
+    else if (rank_mode == 1) hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1, 32>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0, 32>), grid, block, 0, st, a);
   } else {
-    if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0>), grid, block, 0, st, a);
+    const dim3 block(256);
+    if (rank_mode == 2) {  // half-size tiles: two buffers fit where one full image did, the next tile loads during the MFMAs
+      if (table) hipLaunchKernelGGL((filter_kernel<NG, 2, true, 2, 128>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2, 128>), grid, block, 0, st, a);
+    } else if (rank_mode == 1) {  // full images: one buffer, three workgroups per CU (two buffers cost the third: measured slower)
+      if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1, 128>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 1, 128>), grid, block, 0, st, a);
+    } else {
+      if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 0, 128>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((filter_kernel<NG, 1, false, 0, 128>), grid, block, 0, st, a);
+    }
   }
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
 
-vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, int rank_mode, hipStream_t st) {
+vi_status launch_filter(const FilterArgs &a, uint32_t dq, uint32_t nitems, int rank_mode, uint32_t gq, hipStream_t st) {
   switch (dq / 2) {  // dq is a multiple of 4
-    case 2: return launch_filter_t<2>(a, nitems, rank_mode, st);
-    case 4: return launch_filter_t<4>(a, nitems, rank_mode, st);
-    case 6: return launch_filter_t<6>(a, nitems, rank_mode, st);
-    case 8: return launch_filter_t<8>(a, nitems, rank_mode, st);
-    case 10: return launch_filter_t<10>(a, nitems, rank_mode, st);
-    case 12: return launch_filter_t<12>(a, nitems, rank_mode, st);
-    case 14: return launch_filter_t<14>(a, nitems, rank_mode, st);
-    case 16: return launch_filter_t<16>(a, nitems, rank_mode, st);
+    case 2: return launch_filter_t<2>(a, nitems, rank_mode, gq, st);
+    case 4: return launch_filter_t<4>(a, nitems, rank_mode, gq, st);
+    case 6: return launch_filter_t<6>(a, nitems, rank_mode, gq, st);
+    case 8: return launch_filter_t<8>(a, nitems, rank_mode, gq, st);
+    case 10: return launch_filter_t<10>(a, nitems, rank_mode, gq, st);
+    case 12: return launch_filter_t<12>(a, nitems, rank_mode, gq, st);
+    case 14: return launch_filter_t<14>(a, nitems, rank_mode, gq, st);
+    case 16: return launch_filter_t<16>(a, nitems, rank_mode, gq, st);
     default: return fail(VI_ERR_OTHER, "unsupported dimension for the MFMA filter");
   }
 }
@@ -990,7 +1004,7 @@ bool hi_only_ok() {
   return !(e && *e == '0');
 }
 
-SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2) {
+SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2, uint32_t gq) {
   const double u = 1.01 * std::ldexp(1.0, -24);
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
@@ -1005,6 +1019,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   const double acc = rank_bf16() ? (3.0 * ix.dim + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (ix.dim + 2.0) * u;
   c.e_scale = (float)(acc + 1.01 * std::ldexp(1.0, -18));
   c.xmax2 = xmax2;
+  c.gq = gq;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.ws.stats.p : nullptr;
@@ -1136,10 +1151,10 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
-    VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, st));
+    VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
-    CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2), (uint32_t)nq, P,
+    CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2, kGroupQ), (uint32_t)nq, P,
                        (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
                        ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
@@ -1208,11 +1223,16 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
   // ---- 2. group all (query, probe) pairs by list ----
   uint64_t hstats[6];
-  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, kGroupQ, segb0, hstats, st, true));
+  // queries per rank work item: 128 when lists are shared by many queries of the batch, 32 when a list is probed by a
+  // handful (large balanced indexes): a 128-query group would keep three of its four waves idle
+  const char *gqe = getenv("VI_FILTER_GQ");
+  const uint32_t gq = gqe ? (atoi(gqe) == 32 ? 32u : 128u)
+                          : ((double)nq * P / (double)std::max<uint64_t>(1, nlists) >= 24.0 ? 128u : 32u);
+  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];
-  const uint64_t nrec = hstats[4], nbrec = hstats[3] * 256;  // block records: 2 x 128 per (query group, block) tile
+  const uint64_t nrec = hstats[4], nbrec = hstats[3] * 2 * gq;  // block records: 2 x gq per (query group, block) tile
   if (nrec >= (1ull << 31) || nbrec >= (1ull << 32)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
   VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec) * 4));
@@ -1239,12 +1259,13 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.xmode = env_xmode();
     const int rank_mode = rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0;
     stt.rank_mode = (uint64_t)rank_mode + 1;
-    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_mode, st));
+    stt.group_queries = gq;
+    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_mode, gq, st));
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
   // ---- 4. select ----
   {
-    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2), (uint32_t)nq, P, (uint32_t)k, segb0,
+    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2, gq), (uint32_t)nq, P, (uint32_t)k, segb0,
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }

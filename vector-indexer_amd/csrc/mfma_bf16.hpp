@@ -33,11 +33,11 @@ __device__ __forceinline__ void split8(const float4 &lo4, const float4 &hi4, flo
 // (lane (j, h) reads the 8 consecutive dims 16c+8h.. of vector j with one conflict-free ds_read_b128);
 // 2*NG KiB per 64 vectors when the dims are padded to 8*NG, the same bytes as the f32 values.
 // tile_dma_image copies one image + the 64 squared norms behind it into LDS with LDS-DMA, 4 waves.
-template <int NG>
+template <int NG, int WAVES = 4>
 __device__ __forceinline__ void tile_dma_image(float *tile, const float4 *src, const float *xn, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < NG / 2; ++i) {  // 2*NG pieces of 1 KiB, round-robin over the 4 waves
-    const int piece = wave + 4 * i;
+  for (int i = 0; i < 2 * NG / WAVES; ++i) {  // 2*NG pieces of 1 KiB, round-robin over the waves
+    const int piece = wave + WAVES * i;
     __builtin_amdgcn_global_load_lds(src + piece * 64 + lane, (lds_ptr_t)(tile + piece * 256), 16, 0, 0);
   }
   if (wave == 0) __builtin_amdgcn_global_load_lds(xn + lane, (lds_ptr_t)(tile + 2 * NG * 256), 4, 0, 0);
@@ -61,11 +61,11 @@ __device__ __forceinline__ void glds4_asm(const void *gsrc, float *lds_dst) {
 }
 
 // tile_dma_image with the asm copies (double-buffered loops)
-template <int NG>
+template <int NG, int WAVES = 4>
 __device__ __forceinline__ void tile_dma_image_asm(float *tile, const float4 *src, const float *xn, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < NG / 2; ++i) {
-    const int piece = wave + 4 * i;
+  for (int i = 0; i < 2 * NG / WAVES; ++i) {
+    const int piece = wave + WAVES * i;
     glds16_asm(src + piece * 64 + lane, tile + piece * 256);
   }
   if (wave == 0) glds4_asm(xn + lane, tile + 2 * NG * 256);

@@ -37,7 +37,7 @@ class SearchStats(C.Structure):
                 ("scanned_vectors", u64), ("scan_items", u64), ("ms_total", f32), ("ms_coarse", f32),
                 ("ms_group", f32), ("ms_scan", f32), ("ms_merge", f32), ("fallback_queries", u64),
                 ("filter_tile_blocks", u64), ("filter_rechecked", u64), ("filter_accepted", u64),
-                ("rank_mode", u64)]
+                ("rank_mode", u64), ("group_queries", u64)]
 
 
 class AssignStats(C.Structure):
