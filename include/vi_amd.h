@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VI_AMD_ABI_VERSION 1
+#define VI_AMD_ABI_VERSION 2
 
 typedef enum vi_status {
   VI_OK = 0,
@@ -85,8 +85,8 @@ vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint
                     vi_assign_mode mode, uint64_t *labels, float *dist_out);
 
 /* Same assignment with DEVICE pointers (X_dev n x d, C_dev k x d, labels_dev n u32) on HIP device
- * `device`: nothing crosses PCIe.  stats (optional) reports the MFMA filter's kernel time and how
- * many rows needed the exact-order re-check. */
+ * `device`: nothing crosses PCIe.  stats (optional; zero-initialise it: it carries one optional input) reports the MFMA
+ * filter's kernel time and how many rows needed the exact-order re-check. */
 typedef struct vi_assign_stats {
   uint64_t n, k;
   uint64_t ambiguous_rows; /* rows re-evaluated exactly (VI_ASSIGN_EXACT / brute-force path) */
@@ -94,6 +94,11 @@ typedef struct vi_assign_stats {
                               0 for the exact-order scan kernel alone */
   float ms_total;          /* wall time of the call incl. the exact re-check */
   float ms_filter;         /* HIP-event time of the first-tier MFMA kernel alone */
+  uint64_t tier1_rows;     /* rows the first (bf16 x 3) tier left undecided; ambiguous_rows of them also failed the f32 tier */
+  /* in (optional, zero = off): device buffer of ambiguous_cap u32 that receives the row indices counted in tier1_rows
+   * (a superset of the rows re-evaluated exactly) — lets a test check exactly the rows the margins did not decide */
+  uint32_t *ambiguous_rows_dev;
+  uint64_t ambiguous_cap;
 } vi_assign_stats;
 vi_status vi_assign_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, const float *C_dev,
                            uint64_t k, uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev,

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Experiment harness (diagnostic only): phase times of the MFMA search pipeline on the bench workload under the
+ablation knobs of the rank kernel (VI_FILTER_XMODE bits: 1 tiles not restaged, 2 no ranking epilogue, 8 no block-record
+store, 16 no b1 insertion) and the other environment knobs.  Usage: gpu_rank_exp.py [nprobe ...]; EXP=name picks one
+setting only (for rocprofv3 --pmc runs)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "vector-indexer_amd")]
+import bench  # noqa: E402
+import vector_indexer_py as vip  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n, d, nlist, nq, k = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 128)), int(os.environ.get("NLIST", 4096)), \
+    int(os.environ.get("NQ", 10000)), int(os.environ.get("K", 10))
+xb, xq = bench.make_dataset(n, d, nq, 42, dev)
+if os.environ.get("REAL") == "1":  # real-valued data: bf16 x 3 ranking
+    xb = xb + torch.rand_like(xb) * 0.5
+    xq = xq + torch.rand_like(xq) * 0.5
+work = f"/tmp/vi_rank_exp_{n}_{d}_{nlist}_{os.environ.get('REAL', '0')}"
+if not os.path.exists(work + "/index/index.bin"):
+    vip.build(xb.cpu().numpy(), work, nlist=nlist, now_secs=1_700_000_000)
+index = vip.load(work + "/index", work + "/shards", d)
+index.enable_timing(True)
+D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+
+
+def run(label, n_probe, reps=8, **env):
+    for key, val in env.items():
+        os.environ[key] = str(val)
+    acc = {}
+    for r in range(reps):
+        index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), 0)
+        st = index.last_stats()
+        if r >= 3:
+            for f in ("ms_total", "ms_coarse", "ms_group", "ms_scan", "ms_merge"):
+                acc.setdefault(f, []).append(st[f])
+    for key in env:
+        os.environ.pop(key, None)
+    m = {f[3:]: round(float(np.mean(v)), 3) for f, v in acc.items()}
+    print(f"{label:30s} P={n_probe:3d} {m} items={st['scan_items']} tiles={st['filter_tile_blocks']} "
+          f"fill={st['scanned_vectors'] / max(1, st['filter_tile_blocks'] * 64 * max(1, st['group_queries'])):.2f} "
+          f"mode={st['rank_mode']} gq={st['group_queries']}", flush=True)
+
+
+SETTINGS = [
+    ("default", {}),
+    ("tiles not restaged (x1)", {"VI_FILTER_XMODE": 1}),
+    ("no epilogue (x2)", {"VI_FILTER_XMODE": 2}),
+    ("no brec store (x8)", {"VI_FILTER_XMODE": 8}),
+    ("no restage, no epilogue (x3)", {"VI_FILTER_XMODE": 3}),
+    ("no restage, no store (x9)", {"VI_FILTER_XMODE": 9}),
+    ("gq 32", {"VI_FILTER_GQ": 32}),
+    ("bf16x3 lo planes", {"VI_FILTER_HI_ONLY": 0}),
+    ("segb 16", {"VI_FILTER_SEGB": 16}),
+    ("segb 64", {"VI_FILTER_SEGB": 64}),
+]
+only = os.environ.get("EXP")
+probes = [int(a) for a in sys.argv[1:]] or [16, 32]
+for p in probes:
+    for name, env in SETTINGS:
+        if only and only != name.split(" (")[0] and only != name:
+            continue
+        run(name, p, **env)

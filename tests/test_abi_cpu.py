@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(L, n), f"{n} declared in include/vi_amd.h but not exported"
     assert set(N.SIGNATURES) == names
-    assert N.lib().vi_abi_version() == 1
+    assert N.lib().vi_abi_version() == 2
 
 
 def test_heuristics_match_golden():

@@ -395,3 +395,64 @@ def test_randomized_shapes_parity(seed, tmp_path):
         k = int(rng.choice([1, 2, 10, 33, 64]))
         n_probe = int(rng.choice([1, 2, 7, 16, 40, 64]))
         check_parity(orc, gpu, Q, k, n_probe)
+
+
+def test_any_u64_is_a_legal_external_id(tmp_path):
+    """external ids are arbitrary u64 (api.rs:57-62; shards_tests.rs:412-456 uses huge ids): 2^64-1, 2^63 and 0 are
+    ordinary vectors under every engine — pad slots are told from the list layout, never from the stored id"""
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 50, size=(3000, 16)).astype(np.float32)
+    ext = rng.permutation(3000).astype(np.uint64) + 10
+    special = {0: np.uint64(2 ** 64 - 1), 1: np.uint64(2 ** 63), 2: np.uint64(0), 2999: np.uint64(2 ** 64 - 2)}
+    for row, v in special.items():
+        ext[row] = v
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=12, ext_ids=ext)
+    Q = np.concatenate([X[:8], X[2990:], rng.integers(0, 50, size=(40, 16)).astype(np.float32)])
+    for k, n_probe in [(1, 12), (10, 12), (64, 3)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+    D, I = gpu.search_sync(X[:3], 1, 12)
+    assert I[:, 0].astype(np.uint64).tolist() == [int(special[0]), int(special[1]), 0] and (D[:, 0] == 0).all()
+
+
+def test_out_of_range_probe_lists_are_rejected(tmp_path):
+    """vi_indexer_search_probed_device takes probe lists from the caller (another rank's all-gather): a list id outside
+    the index, an order outside the probe count or a hole before a real probe must come back as InvalidInput — not as a
+    GPU fault (the abort class of round 1's unsorted probe rows)"""
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((4000, 32)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=40)
+    nl = gpu.num_centroids
+    Q = rng.standard_normal((300, 32)).astype(np.float32)
+    hip = _Hip()
+    try:
+        nq, k, P = Q.shape[0], 5, 6
+        xq = hip.upload(Q)
+        probes, order = hip.alloc(nq * P * 4), hip.alloc(nq * P * 4)
+        assert gpu.probe_device(xq, nq, P, probes, order) == P
+        Dg, Ig, Tg = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8), hip.alloc(nq * k * 8)
+        gpu.search_probed_device(xq, nq, k, P, probes, order, Dg, Ig, Tg)   # the genuine lists pass
+        rc, Do, Io = orc.search_batch(Q, k, P)
+        assert (hip.download(Ig, (nq, k), np.int64) == Io).all()
+        good_p, good_o = hip.download(probes, (nq, P), np.uint32), hip.download(order, (nq, P), np.uint32)
+        for what, (pi, pj, pv, oi, oj, ov) in {
+                "list id == nlists": (17, 3, nl, None, None, None),
+                "list id far out": (299, 5, 0x7FFFFFFF, None, None, None),
+                "hole before a real probe": (5, 0, 0xFFFFFFFF, None, None, None),
+                "order out of range": (None, None, None, 100, 2, P)}.items():
+            bp, bo = good_p.copy(), good_o.copy()
+            if pi is not None:
+                bp[pi, pj] = pv
+            if oi is not None:
+                bo[oi, oj] = ov
+            with pytest.raises(N.ViError) as e:
+                gpu.search_probed_device(xq, nq, k, P, hip.upload(bp), hip.upload(bo), Dg, Ig, Tg)
+            assert e.value.kind == "InvalidInput", what
+        # trailing empty markers are legal (a rank whose coarse step found fewer lists)
+        bp = good_p.copy(); bo = good_o.copy()
+        bp[7, P - 1] = 0xFFFFFFFF; bo[7, P - 1] = 0xFFFFFFFF
+        gpu.search_probed_device(xq, nq, k, P, hip.upload(bp), hip.upload(bo), Dg, Ig, Tg)
+        # and the handle is still healthy
+        gpu.search_probed_device(xq, nq, k, P, probes, order, Dg, Ig, Tg)
+        assert (hip.download(Ig, (nq, k), np.int64) == Io).all()
+    finally:
+        hip.close()

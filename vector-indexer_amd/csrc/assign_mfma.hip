@@ -365,6 +365,11 @@ __global__ void gather_amb_rows_kernel(const float *X, const uint32_t *rows, uin
   reinterpret_cast<float4 *>(out)[t] = reinterpret_cast<const float4 *>(X + (size_t)rows[i] * d)[c];
 }
 
+__global__ void export_rows_kernel(const uint32_t *rows, uint32_t n, uint32_t base, uint32_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rows[i] + base;
+}
+
 __global__ void scatter_amb_labels_kernel(const uint32_t *rows, uint32_t nrows, const uint32_t *lab_c, uint32_t *labels) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nrows) labels[rows[i]] = lab_c[i];
@@ -435,7 +440,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     a.img = (const float4 *)ws.img.p;
     a.cn = ws.cnpad.p;
   }
-  uint64_t total_amb = 0, total_tier2 = 0;
+  uint64_t total_amb = 0, total_tier1 = 0, total_tier2 = 0;
   float ms_filter = 0.0f;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (stats) { VI_HIP(hipEventCreate(&ev0)); VI_HIP(hipEventCreate(&ev1)); }
@@ -465,6 +470,14 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     VI_HIP(hipMemcpyAsync(&namb, ws.namb.p, 4, hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
     if (stats) { float ms = 0; (void)hipEventElapsedTime(&ms, ev0, ev1); ms_filter += ms; }
+    if (stats && stats->export_rows && namb && stats->exported < stats->export_cap) {
+      const uint32_t m2 = (uint32_t)std::min<uint64_t>(namb, stats->export_cap - stats->exported);
+      hipLaunchKernelGGL(export_rows_kernel, dim3((m2 + 255) / 256), dim3(256), 0, st, ws.amb_list.p, m2, (uint32_t)p0,
+                         stats->export_rows + stats->exported);
+      VI_HIP(hipGetLastError());
+      stats->exported += m2;
+    }
+    total_tier1 += namb;
     if (namb && bf16 && namb >= 2048) {
       // second tier: the bf16 margin is ~5x the f32 one, so most of its ambiguous rows are decided by the f32
       // MFMA kernel on the gathered rows; only what that leaves goes through the exact-order scan
@@ -500,6 +513,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   if (stats) {
     stats->ambiguous_rows = total_amb;
     stats->tier2_rows = total_tier2;
+    stats->tier1_rows = total_tier1;
     stats->ms_filter = ms_filter;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

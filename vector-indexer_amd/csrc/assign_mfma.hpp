@@ -8,8 +8,11 @@ namespace vi {
 
 struct MfmaAssignStats {
   uint64_t ambiguous_rows = 0;  // rows re-evaluated by the exact-order scan
-  uint64_t tier2_rows = 0;      // rows the bf16 pass left to the f32 MFMA pass
+  uint64_t tier1_rows = 0;      // rows the first MFMA pass left undecided
+  uint64_t tier2_rows = 0;      // ... of which went through the f32 MFMA pass (the rest straight to the exact scan)
   float ms_filter = 0.0f;       // HIP-event time of the MFMA kernel launches
+  uint32_t *export_rows = nullptr;  // optional (device): receives the first-tier ambiguous row indices
+  uint64_t export_cap = 0, exported = 0;
 };
 
 struct MfmaAssignWs {

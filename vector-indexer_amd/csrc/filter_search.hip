@@ -72,23 +72,28 @@ constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
 constexpr uint32_t kB2Flag = 0x80000000u;  // record position flag: the value is a block's SECOND smallest
 constexpr float kBig = 3.0e38f;            // norm of pad slots inside the kernel (finite: low bits are reused)
 
-__global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, const uint64_t *ext_ids,
-                                  float *xnorm, uint32_t *xmax_bits) {
+__global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, float *xnorm, uint32_t *xmax_bits) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
-  float out = kBig;  // pad slots never rank (finite: the kernel reuses the low mantissa bits)
-  if (!ext_ids || ext_ids[s] != ~0ull) {
-    double acc = 0.0;
-    const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
-    for (uint32_t qd = 0; qd < dq; ++qd) {
-      const float4 v = p[(size_t)qd * kWave];
-      acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-    }
-    out = (float)acc;
-    if (out < kBig) atomicMax(xmax_bits, __float_as_uint(out));
-    out = fminf(out, kBig);
+  double acc = 0.0;  // (pad slots hold zeros: they are marked by pad_norms_kernel from the list layout afterwards)
+  const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
+  for (uint32_t qd = 0; qd < dq; ++qd) {
+    const float4 v = p[(size_t)qd * kWave];
+    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
   }
-  xnorm[s] = out;
+  float out = (float)acc;
+  if (out < kBig) atomicMax(xmax_bits, __float_as_uint(out));
+  xnorm[s] = fminf(out, kBig);
+}
+
+// pad slots (positions len .. 64*ceil(len/64) of every list) never rank: the mask comes from the layout, not from the
+// stored ids — the reference accepts ANY u64 as external_id (api.rs:57-62), 2^64-1 included
+__global__ void pad_norms_kernel(const uint32_t *first_block, const uint32_t *list_len, uint32_t nlists, float *xnorm) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t l = t >> 6, j = t & 63u;
+  if (l >= nlists) return;
+  const uint32_t len = list_len[l], p = len + j;
+  if (p < ((len + 63u) & ~63u)) xnorm[(size_t)first_block[l] * kWave + p] = kBig;  // (finite: the kernel reuses the low mantissa bits)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -595,7 +600,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const float scale = fmaxf(mk + qn, 0.0f) + E;
     return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
   };
-  uint32_t npick = 0, ncons = 0, n_exact = 0, n_consult = 0;
+  uint32_t npick = 0, ncons = 0, n_exact = 0, n_consult = 0, n_full = 0, n_b2 = 0, n_whole = 0;
   WaveTopK s1;
   // block records waiting in `consult`; mode 0 = their values refine the threshold, mode 1 = stage 2
   float thr = INFINITY;
@@ -657,6 +662,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       } else {
         n_consult += cnt;
         const bool whole = live && (B.w <= thr || distrust);  // rows missing from the record are only known to be >= b4
+        n_whole += (uint32_t)__popcll(__ballot(whole));
         const float bv[3] = {B.x, B.y, B.z};
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -800,6 +806,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     const float4 T = group_values(gidx, live);
     const bool full = live && (T.w <= thr || distrust);
+    n_full += (uint32_t)__popcll(__ballot(full));
     // positions are only needed by chunks that list something at or below thr
     uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
     if (live && !full && T.x <= thr) Pp = c.gpos[gbase + gidx];
@@ -822,6 +829,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
         if (jx != i && pass[jx] && is2[jx] && blk[jx] == blk[i]) single = false;
       push_single(single, r, tp[i] & kPosMask);
       // a listed second-smallest says nothing about its block's other rows: consult the block record
+      n_b2 += (uint32_t)__popcll(__ballot(pass[i] && is2[i]));
       push_consult(pass[i] && is2[i], r, blk[i], hh, 1);
     }
     // the fourth-smallest listed value is at or below thr: consult every block record of the group
@@ -832,6 +840,10 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   if (c.dbg && lane == 0) {
     atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
     atomicAdd(&c.dbg[7], (unsigned long long)n_consult);
+    atomicAdd(&c.dbg[8], (unsigned long long)(any_full ? 1u : 0u));
+    atomicAdd(&c.dbg[9], (unsigned long long)n_full);
+    atomicAdd(&c.dbg[10], (unsigned long long)n_b2);
+    atomicAdd(&c.dbg[11], (unsigned long long)n_whole);
   }
 }
 
@@ -1042,7 +1054,10 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
   if (nslots) {
     hipLaunchKernelGGL(slot_norms_kernel, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, ix->stream,
-                       (const float4 *)ix->lists.blocks.p, ix->dq, nslots, ix->ext_ids.p, ix->xnorm.p, mx.p);
+                       (const float4 *)ix->lists.blocks.p, ix->dq, nslots, ix->xnorm.p, mx.p);
+    if (ix->nlists)
+      hipLaunchKernelGGL(pad_norms_kernel, dim3((uint32_t)((ix->nlists * 64 + 255) / 256)), dim3(256), 0, ix->stream,
+                         ix->list_first_block.p, ix->list_len.p, (uint32_t)ix->nlists, ix->xnorm.p);
     VI_HIP(hipGetLastError());
   }
   uint32_t bits = 0;
@@ -1057,8 +1072,7 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
   if (cslots) {
     hipLaunchKernelGGL(slot_norms_kernel, dim3((uint32_t)((cslots + 255) / 256)), dim3(256), 0, ix->stream,
-                       (const float4 *)ix->centroids.blocks.p, ix->dq, cslots, (const uint64_t *)nullptr,
-                       ix->cent_xnorm.p, mx.p);
+                       (const float4 *)ix->centroids.blocks.p, ix->dq, cslots, ix->cent_xnorm.p, mx.p);
     VI_HIP(hipGetLastError());
     const uint64_t npad = cslots - ix->nlists;
     if (npad) {
@@ -1133,7 +1147,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.gval.reserve(nq * recs * 4));
   VI_TRY(ws.gpos.reserve(nq * recs * 4));
   VI_TRY(ws.brec.reserve((uint64_t)ngroups * ix.centroids.nblocks * 256 * 4));
-  VI_TRY(ws.stats.reserve(8));
+  VI_TRY(ws.stats.reserve(16));
   if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
     VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
     VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
@@ -1203,8 +1217,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
-  VI_TRY(ws.stats.reserve(8));
-  if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 2 * sizeof(uint64_t), st));
+  VI_TRY(ws.stats.reserve(16));
+  if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
   if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
@@ -1274,10 +1288,14 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
   if (timing && getenv("VI_FILTER_STATS")) {
-    uint64_t dbg[8];
+    uint64_t dbg[12];
     VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
     stt.filter_rechecked = dbg[6]; stt.filter_accepted = dbg[7];
+    if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
+      fprintf(stderr, "select stats: exact %llu consult %llu queries_with_full_group %llu full_groups %llu listed_b2 %llu whole_lane_blocks %llu\n",
+              (unsigned long long)dbg[6], (unsigned long long)dbg[7], (unsigned long long)dbg[8], (unsigned long long)dbg[9],
+              (unsigned long long)dbg[10], (unsigned long long)dbg[11]);
   }
   return VI_OK;
 }

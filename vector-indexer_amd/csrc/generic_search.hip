@@ -118,12 +118,16 @@ __global__ void shard_order_keys_kernel(const uint32_t *probes, const uint32_t *
   const uint32_t q = blockIdx.x;
   for (uint32_t s = threadIdx.x; s < nshards; s += blockDim.x) fa[s] = kNoPos;
   __syncthreads();
-  for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) atomicMin(&fa[list_shard[probes[(size_t)q * P + r]]], r);  // probes < nlists: rows hold >= P real keys
+  // (probes < nlists: P <= nlists, so a sorted row starts with P real keys; a shard id out of range is skipped)
+  for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) {
+    const uint32_t sh = list_shard[probes[(size_t)q * P + r]];
+    if (sh < nshards) atomicMin(&fa[sh], r);
+  }
   __syncthreads();
   const uint32_t Lp = 1u << logLp;
   for (uint32_t r = threadIdx.x; r < Lp; r += blockDim.x)
     keys[((size_t)q << logLp) + r] =
-        r < P ? (((uint64_t)fa[list_shard[probes[(size_t)q * P + r]]] << 32) | r) : ~0ull;
+        r < P ? (((uint64_t)fa[min(list_shard[probes[(size_t)q * P + r]], nshards - 1u)] << 32) | r) : ~0ull;
 }
 
 // per query: candidate offsets of each probe in reference candidate order (sequential prefix)

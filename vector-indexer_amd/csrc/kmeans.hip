@@ -461,6 +461,7 @@ vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t
   VI_HIP(hipEventCreate(&e1));
   VI_HIP(hipEventRecord(e0, cx.st));
   MfmaAssignStats ms;
+  if (stats) { ms.export_rows = stats->ambiguous_rows_dev; ms.export_cap = stats->ambiguous_cap; }
   vi_status rc;
   const bool hier = mode == VI_ASSIGN_REFERENCE && k > 100;
   if (hier) rc = assign_hier_device(cx, Xd, n, Cd, k, d, seed, labels_dev);
@@ -471,6 +472,7 @@ vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t
     if (stats) {
       stats->n = n; stats->k = k;
       stats->ambiguous_rows = ms.ambiguous_rows;
+      stats->tier1_rows = ms.tier1_rows;
       stats->ms_filter = ms.ms_filter;
       stats->used_mfma = (!hier && ms.ms_filter > 0.0f) ? 1u : 0u;
       (void)hipEventElapsedTime(&stats->ms_total, e0, e1);

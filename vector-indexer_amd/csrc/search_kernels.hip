@@ -454,23 +454,38 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   }
 }
 
-__global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t n, uint32_t P,
+// (list ids are range-checked wherever they index: a caller-supplied probe list, vi_indexer_search_probed_device, is
+// validated up front by validate_probes_kernel, and a stray word can then still not fault the GPU)
+__global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t n, uint32_t P,
                                  uint32_t *cnt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t l = probes[i];
-  if (l != kNoPos && list_len[l] > 0) atomicAdd(&cnt[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
+  if (l < nlists && list_len[l] > 0) atomicAdd(&cnt[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
 }
 
-__global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t P, uint32_t *cursor,
-                                     uint32_t *pairs, uint32_t total, const uint32_t *seg_start, uint32_t *pair_pos) {
+__global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t P,
+                                     uint32_t *cursor, uint32_t *pairs, uint32_t total, const uint32_t *seg_start,
+                                     uint32_t *pair_pos) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint32_t l = probes[i];
-  if (l == kNoPos || list_len[l] == 0) return;
+  if (l >= nlists || list_len[l] == 0) return;
   const uint32_t pos = atomicAdd(&cursor[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
   pairs[pos] = i;  // slot id = q*P + rank
   if (pair_pos) pair_pos[i] = pos - seg_start[l];  // MFMA path: where the pair sits among the pairs of its list
+}
+
+// caller-supplied probe lists (multi-GPU: another rank's coarse step): every probe must name a list of this index or be the
+// empty marker, the real probes of a row must come first, and the candidate-order ranks must be a rank < P or the marker
+__global__ void validate_probes_kernel(const uint32_t *probes, const uint32_t *order, uint32_t total, uint32_t P,
+                                       uint32_t nlists, uint32_t *bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t l = probes[i], g = order[i];
+  bool ok = (l < nlists && g < P) || (l == kNoPos);
+  if (ok && l != kNoPos && (i % P) != 0 && probes[i - 1] == kNoPos) ok = false;
+  if (!ok) atomicOr(bad, 1u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -551,7 +566,8 @@ __global__ void __launch_bounds__(kBlockThreads) merge_partials_kernel(uint64_t 
   float hd = INFINITY;
   uint64_t ht = ~0ull;
   int64_t hi = -1;
-  if (live) { hd = Dp[base]; ht = Tp[base]; hi = Ip[base]; live = hi >= 0; }
+  // an empty slot is marked by its tie key (ids are arbitrary u64: one >= 2^63 reads as a negative i64)
+  if (live) { hd = Dp[base]; ht = Tp[base]; hi = Ip[base]; live = ht != ~0ull; }
   uint32_t found = 0;
   for (uint32_t i = 0; i < k; ++i) {
     // two-level key: distance bits first, then the 64-bit tie key
@@ -564,7 +580,7 @@ __global__ void __launch_bounds__(kBlockThreads) merge_partials_kernel(uint64_t 
       D[q * k + i] = hd;
       I[q * k + i] = hi;
       ++head;
-      if (head < k) { hd = Dp[base + head]; ht = Tp[base + head]; hi = Ip[base + head]; live = hi >= 0; }
+      if (head < k) { hd = Dp[base + head]; ht = Tp[base + head]; hi = Ip[base + head]; live = ht != ~0ull; }
       else live = false;
     }
     ++found;
@@ -856,7 +872,9 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
     const uint8_t *lo = nullptr, *hi = nullptr;
     for (uint32_t i = 0; i < f.num_lists(); ++i) {
       const ShardListView &lv = f.list(i);
-      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0) continue;
+      // (a file with duplicate centroid ids: only the first entry exists for the reference's linear find,
+      // shards.rs:257-265 — a later one must not be uploaded over the blocks sized from the first)
+      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0 || f.find(lv.centroid_id) != &lv) continue;
       if (!lo || lv.records < lo) lo = lv.records;
       const uint8_t *end = lv.records + (uint64_t)lv.num_vectors * stride;
       if (!hi || end > hi) hi = end;
@@ -864,12 +882,13 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
     if (!lo) continue;
     for (uint32_t i = 0; i < f.num_lists(); ++i) {
       const ShardListView &lv = f.list(i);
-      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0) continue;
+      if (lv.centroid_id >= k || meta.c2s[lv.centroid_id] != s || lv.num_vectors == 0 || f.find(lv.centroid_id) != &lv) continue;
       const uint32_t nb = (lv.num_vectors + kWave - 1) / kWave;
       for (uint32_t b = R; b < nb; b += W) {
         src.push_back((uint64_t)(lv.records - lo) + (uint64_t)b * kWave * stride);
         nv.push_back(std::min<uint32_t>(kWave, lv.num_vectors - b * kWave));
         dst.push_back(h_first[lv.centroid_id] + (b - R) / W);
+        if (dst.back() >= total_blocks) return fail(VI_ERR_INVALID_DATA, "shard_%llu.bin: list blocks exceed the index layout", (unsigned long long)s);
       }
     }
     VI_TRY(repack_upload(lo, (size_t)(hi - lo), src, nv, dst, dim, dq, stride, (uint32_t)kVectorMetaBytes, 8,
@@ -1018,14 +1037,25 @@ vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uin
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
+  VI_TRY(ws.probe_flag.reserve(1));
+  const uint32_t total = (uint32_t)(nq * P);
+  VI_HIP(hipMemsetAsync(ws.probe_flag.p, 0, 4, st));
+  hipLaunchKernelGGL(validate_probes_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes_in, order_in, total, P,
+                     (uint32_t)nlists, ws.probe_flag.p);
+  VI_HIP(hipGetLastError());
+  uint32_t bad = 0;
+  VI_HIP(hipMemcpyAsync(&bad, ws.probe_flag.p, 4, hipMemcpyDeviceToHost, st));
   VI_HIP(hipMemcpyAsync(ws.probes.p, probes_in, nq * P * 4, hipMemcpyDeviceToDevice, st));
   VI_HIP(hipMemcpyAsync(ws.gorder.p, order_in, nq * P * 4, hipMemcpyDeviceToDevice, st));
+  VI_HIP(hipStreamSynchronize(st));
+  if (bad)
+    return fail(VI_ERR_INVALID_INPUT, "probe lists out of range: every probe must be < %llu (or the empty marker 0xFFFFFFFF "
+                "after the last real probe of a row) and every order < n_probe_eff", (unsigned long long)nlists);
   if (histogram) {
-    const uint32_t total = (uint32_t)(nq * P);
     VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p, ix.list_len.p, total, P,
-                       ws.cnt.p);
+    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p, ix.list_len.p,
+                       (uint32_t)nlists, total, P, ws.cnt.p);
     VI_HIP(hipGetLastError());
   }
   return VI_OK;
@@ -1072,8 +1102,8 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
-                       ix.list_len.p, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p,
-                       (uint32_t *)nullptr);
+                       ix.list_len.p, (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total,
+                       ws.seg_start.p, (uint32_t *)nullptr);
     VI_HIP(hipGetLastError());
   }
   VI_HIP(hipEventSynchronize(ix.ev[5]));
@@ -1156,7 +1186,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     Qd = ws.q.p; Dd = ws.D.p; Id = ws.I.p; Td = nullptr;
   }
   VI_TRY(ws.counts.reserve(nq));
-  VI_TRY(ws.stats.reserve(8));
+  VI_TRY(ws.stats.reserve(16));
   uint64_t *slots = nullptr;
   if (io.V) { VI_TRY(ws.slots.reserve(nq * k)); slots = ws.slots.p; }
 
@@ -1247,12 +1277,12 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pairs.reserve(total));
   VI_TRY(ws.pair_pos.reserve(total));
   VI_TRY(ws.tile_start.reserve(nlists + 1));
-  VI_TRY(ws.stats.reserve(8));
+  VI_TRY(ws.stats.reserve(16));
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6], [7] belong to the MFMA path's select
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, total, P,
-                       ws.cnt.p);
+    hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
+                       (uint32_t)nlists, total, P, ws.cnt.p);
   }
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
@@ -1261,8 +1291,8 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.ev[5], st));
-  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p, P,
-                     ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
+  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
+                     (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
   VI_HIP(hipGetLastError());
   VI_HIP(hipEventSynchronize(ix.ev[5]));
   return VI_OK;

@@ -172,7 +172,7 @@ struct Reader {
   }
   bool byte(uint8_t *v) { if (off >= len) return false; *v = p[off++]; return true; }
   bool floats(float *dst, uint64_t n) {
-    if (n * 4 > len - off) return false;
+    if (n > (len - off) / 4) return false;
     std::memcpy(dst, p + off, n * 4);
     off += n * 4;
     return true;
@@ -247,11 +247,11 @@ vi_status read_vectors_from_file(const std::string &path, std::vector<VectorFile
   while (r.off < r.len) {
     const size_t batch_start_count = out->size();
     uint64_t cnt;
-    bool ok = r.varint(&cnt);
+    bool ok = r.varint(&cnt) && cnt <= r.len - r.off;  // every record takes at least three bytes
     for (uint64_t i = 0; ok && i < cnt; ++i) {
       VectorFileRecord rec;
       uint64_t vl;
-      ok = r.varint(&rec.id) && r.varint(&vl) && vl * 4 <= r.len - r.off;
+      ok = r.varint(&rec.id) && r.varint(&vl) && vl <= (r.len - r.off) / 4;  // (vl * 4 would wrap for vl >= 2^62)
       if (ok) { rec.values.resize(vl); ok = r.floats(rec.values.data(), vl) && r.varint(&rec.meta); }
       if (ok) out->push_back(std::move(rec));
     }

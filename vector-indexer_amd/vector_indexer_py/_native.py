@@ -42,7 +42,7 @@ class SearchStats(C.Structure):
 
 class AssignStats(C.Structure):
     _fields_ = [("n", u64), ("k", u64), ("ambiguous_rows", u64), ("used_mfma", u32), ("ms_total", f32),
-                ("ms_filter", f32)]
+                ("ms_filter", f32), ("tier1_rows", u64), ("ambiguous_rows_dev", vp), ("ambiguous_cap", u64)]
 
 
 SIGNATURES = {
