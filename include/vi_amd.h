@@ -117,6 +117,61 @@ vi_status vi_kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k,
                              float early_stop_threshold, uint64_t seed, vi_assign_mode mode,
                              float *centroids_out, uint64_t *labels_out, uint64_t *iters_run);
 
+/* The same two entry points with DEVICE pointers on HIP device `device` (X_dev n x d, centroids_dev k x d, labels_dev n
+ * u32; labels_dev may be NULL for vi_kmeans_mini_batch_device to skip the final assignment): the points never cross PCIe
+ * — config C3's 5 GB would take longer to upload than to assign. */
+vi_status vi_kmeans_mini_batch_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
+                                      uint64_t max_iters, float early_stop_threshold, uint64_t seed, vi_assign_mode mode,
+                                      float *centroids_dev, uint32_t *labels_dev, uint64_t *iters_run);
+vi_status vi_kmeans_parallel_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
+                                    uint64_t max_iters, float early_stop_threshold, uint64_t seed, vi_assign_mode mode,
+                                    float *centroids_dev, uint32_t *labels_dev, uint64_t *iters_run);
+
+/* ---- k-means with the points SHARDED over the GPUs of a node (one process per GPU; extension: the reference has no
+ *      distributed mode).  The collectives stay in the caller (RCCL through torch.distributed, as for search):
+ *
+ *   training   k-means++ seeding, the mini-batches and the empty-cluster re-seeds read only the rows the rand stream
+ *              names (50 000 + k + iterations x (batch + empty clusters) of them).  vi_kmeans_mini_batch_train /
+ *              vi_kmeans_pp_init run that loop over a vi_row_source: the caller's fetch_rows gathers the named rows
+ *              from their owner ranks (a collective every rank enters with the same row list: every rank replays the
+ *              same rand 0.8.5 stream; rank 0's centroids are broadcast afterwards, which pins them bit for bit).
+ *   assignment vi_assign_device on every rank's own points (labels stay local) — the O(N k D) part.
+ *   Lloyd      per iteration: vi_assign_device, vi_kmeans_partial_sums_device (this rank's sums k x d and counts k),
+ *              all-reduce(sum) of both, vi_kmeans_finish_update_device (means, RMS movement, empty clusters);
+ *              empty clusters are re-seeded with rows drawn by rank 0's vi_rng and fetched like the training rows.
+ *              Sums combined over ranks associate differently from the reference's single pass: centroids agree
+ *              to rounding (compare with a tolerance), labels of the first iteration exactly. */
+typedef struct vi_row_source {
+  void *ctx;
+  /* out_dev[i, 0..d) = data row global_rows[i] for i < n_rows, complete on return; 0 = ok */
+  int (*fetch_rows)(void *ctx, const uint64_t *global_rows, uint64_t n_rows, float *out_dev);
+} vi_row_source;
+/* the loop of run_kmeans_mini_batch (src/kmeans.rs:64-142) without its final assignment; centroids_dev k x d */
+vi_status vi_kmeans_mini_batch_train(int32_t device, const vi_row_source *rows, uint64_t n_global, uint32_t d, uint64_t k,
+                                     uint64_t max_iters, float early_stop_threshold, uint64_t seed,
+                                     float *centroids_dev, uint64_t *iters_run);
+/* kmeans_plus_plus_init (src/kmeans.rs:154-310) alone (the start of run_kmeans_parallel) */
+vi_status vi_kmeans_pp_init(int32_t device, const vi_row_source *rows, uint64_t n_global, uint32_t d, uint64_t k,
+                            uint64_t seed, float *centroids_dev);
+/* update_centroids_parallel (src/kmeans.rs:674-719), this rank's share: sums_dev k x d f32, counts_dev k u32 */
+vi_status vi_kmeans_partial_sums_device(int32_t device, const float *X_dev, uint64_t n_local, uint32_t d,
+                                        const uint32_t *labels_dev, uint64_t k, float *sums_dev, uint32_t *counts_dev);
+/* ... and what follows the all-reduce: C_new = sums / counts (zero rows for empty clusters), *delta_out =
+ * compute_centroid_delta(C_new, C_prev) (src/kmeans.rs:334-351), empty_out (optional, host, k u32) / *n_empty = the
+ * clusters handle_empty_clusters (src/kmeans.rs:313-331) re-seeds, ascending */
+vi_status vi_kmeans_finish_update_device(int32_t device, const float *sums_dev, const uint32_t *counts_dev, uint64_t k,
+                                         uint32_t d, const float *C_prev_dev, float *C_new_dev, float *delta_out,
+                                         uint32_t *empty_out, uint64_t *n_empty);
+/* compute_centroid_delta (src/kmeans.rs:334-351) of two device tables (after the re-seed, as the reference orders it) */
+vi_status vi_kmeans_centroid_delta_device(int32_t device, const float *C_new_dev, const float *C_prev_dev, uint64_t k,
+                                          uint32_t d, float *delta_out);
+/* rand 0.8.5 StdRng::seed_from_u64(seed) and Rng::gen_range(low..high) on usize — the stream the reference draws
+ * re-seed rows from (src/kmeans.rs:31,325) */
+typedef struct vi_rng vi_rng;
+vi_rng *vi_rng_seed_from_u64(uint64_t seed);
+uint64_t vi_rng_gen_range(vi_rng *rng, uint64_t low, uint64_t high);
+void vi_rng_free(vi_rng *rng);
+
 /* ---- shard files ------------------------------------------------------------------ */
 /* replaces Shard::save_to(&self, shards_dir) — src/shards.rs:68-177.  Lists flattened:
  * list i owns vectors [list_off[i], list_off[i+1]).  Byte-identical file layout. */

@@ -17,6 +17,7 @@ import pytest
 
 import oracle_lib as O
 import vector_indexer_py as vip
+from hiprt import Hip
 from vector_indexer_py import _native as N
 
 pytestmark = pytest.mark.gpu
@@ -44,19 +45,29 @@ def assert_same(Dg, Ig, Do, Io, what):
 # ---------------------------------------------------------------------------------------------------------------
 # C2: the headline search configuration at full size
 # ---------------------------------------------------------------------------------------------------------------
+def sift_shaped(n, d, nq, seed):
+    """numpy port of bench.py:make_dataset (same recipe, numpy's generator): non-negative integer-valued f32 in
+    [0, 218] drawn from a 2048-component mixture; queries are held-out draws of the same mixture"""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((2048, d), dtype=np.float32) * 30.0 + 60.0
+
+    def draw(m):
+        out = np.empty((m, d), dtype=np.float32)
+        for s in range(0, m, 100_000):
+            e = min(m, s + 100_000)
+            x = centers[rng.integers(0, 2048, e - s)] + rng.standard_normal((e - s, d), dtype=np.float32) * 14.0
+            out[s:e] = np.clip(np.round(np.abs(x)), 0, 218)
+        return out
+    return draw(n), draw(nq)
+
+
 @pytest.fixture(scope="module")
 def c2(tmp_path_factory):
-    import torch
-    import bench
-    dev = torch.device("cuda", 0)
-    xb, xq = bench.make_dataset(1_000_000, 128, 10_000, 42, dev)
+    xb, xq = sift_shaped(1_000_000, 128, 10_000, 42)
     work = str(tmp_path_factory.mktemp("c2"))
-    gpu = vip.build(xb.cpu().numpy(), work, nlist=4096, now_secs=1_700_000_000)
+    gpu = vip.build(xb, work, nlist=4096, now_secs=1_700_000_000)
     orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
-    Q = xq[:1000].cpu().numpy()
-    del xb
-    torch.cuda.empty_cache()
-    return gpu, orc, Q, xq
+    return gpu, orc, xq[:1000].copy(), xq
 
 
 @pytest.mark.parametrize("n_probe", [16, 32])
@@ -77,20 +88,24 @@ def test_c2_sift1m_shape_ids_and_distance_bits(c2, n_probe, monkeypatch):
 def test_c2_full_batch_device_entry_matches_host_entry(c2):
     """the bench's call (vi_indexer_search_device, 10 000 device-resident queries) returns what the host-pointer call
     returns for the same queries: the first 1 000 rows are the oracle-checked ones"""
-    import torch
     gpu, orc, Q, xq = c2
     nq, k = xq.shape[0], 10
-    D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
-    I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
-    for n_probe in (16, 32):
-        gpu.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), 0)
-        rc, Do, Io = orc.search_batch(Q, k, n_probe, O.usable_cpus())
-        assert_same(D[:1000].cpu().numpy(), I[:1000].cpu().numpy(), Do, Io, f"device entry nprobe {n_probe}")
-        # the other 9 000: internal consistency (ascending, ids valid) — the oracle at 2 k queries/s checks a sample
-        Dh = D.cpu().numpy()
-        assert (np.diff(Dh, axis=1) >= 0).all()
-        Ih = I.cpu().numpy()
-        assert ((Ih >= 0) & (Ih < 1_000_000)).all()
+    hip = Hip()
+    try:
+        xd = hip.upload(xq)
+        D, I = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+        for n_probe in (16, 32):
+            gpu.search_device(xd, nq, k, n_probe, D, I, 0)
+            Dh, Ih = hip.download(D, (nq, k), np.float32), hip.download(I, (nq, k), np.int64)
+            rc, Do, Io = orc.search_batch(Q, k, n_probe, O.usable_cpus())
+            assert_same(Dh[:1000], Ih[:1000], Do, Io, f"device entry nprobe {n_probe}")
+            # the other 9 000: internal consistency (ascending, ids valid); the oracle checks a further sample
+            assert (np.diff(Dh, axis=1) >= 0).all() and ((Ih >= 0) & (Ih < 1_000_000)).all()
+            rows = np.arange(1000, nq, 45)
+            rc, Do, Io = orc.search_batch(xq[rows], k, n_probe, O.usable_cpus())
+            assert_same(Dh[rows], Ih[rows], Do, Io, f"device entry nprobe {n_probe}, sampled rows")
+    finally:
+        hip.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -125,39 +140,38 @@ def test_c3_exact_assign_k16384(monkeypatch):
     """VI_ASSIGN_EXACT == assign_points_brute_force (src/kmeans.rs:462-470) at k=16384 D=128: every row the bf16 x 3 tier
     left undecided (they go through the f32 MFMA tier and the exact scan — the two fallback tiers) plus 20 000 sampled
     rows, N=1e6 rows ranked (the oracle needs ~3 s per 30 000 rows; N is bounded by that, k and D are BASELINE's)"""
-    import torch
-    dev = torch.device("cuda", 0)
     n, d, k = 1_000_000, 128, 16384
-    g = torch.Generator(device=dev)
-    g.manual_seed(42)
-    X = torch.randn(n, d, generator=g, device=dev)
-    Cn = X[torch.randperm(n, generator=g, device=dev)[:k]].contiguous()
+    rng = np.random.default_rng(42)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    Cn = X[rng.choice(n, k, replace=False)].copy()
     # duplicate centroids and exact ties must resolve to the lower index (strict '<', kmeans.rs:364-370)
     Cn[k - 1] = Cn[7]
     Cn[1000] = Cn[999]
-    lab = torch.empty(n, dtype=torch.int32, device=dev)
-    amb = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    st = N.AssignStats()
-    st.ambiguous_rows_dev = amb.data_ptr()
-    st.ambiguous_cap = n
-    N.check(N.lib().vi_assign_device(0, X.data_ptr(), n, d, Cn.data_ptr(), k, 42, N.VI_ASSIGN_EXACT, lab.data_ptr(),
-                                     C.byref(st)))
-    assert st.used_mfma == 1
-    n_amb = int(st.tier1_rows)
-    assert 0 < n_amb < n // 10 and int(st.ambiguous_rows) <= n_amb
-    rows_amb = amb[:n_amb].cpu().numpy().astype(np.int64)
-    assert (rows_amb >= 0).all() and np.unique(rows_amb).size == n_amb
-    rng = np.random.default_rng(1)
-    rows = np.unique(np.concatenate([rows_amb, rng.choice(n, 20_000, replace=False), [0, n - 1]]))
-    Xh = X[torch.from_numpy(rows).to(dev)].cpu().numpy()
-    want = O.assign(Xh, Cn.cpu().numpy(), mode="brute")
-    got = lab.cpu().numpy()[rows].astype(np.uint64)
-    bad = np.nonzero(got != want)[0]
-    assert bad.size == 0, f"{bad.size} of {rows.size} labels differ (first row {rows[bad[0]]}: {got[bad[0]]} vs {want[bad[0]]})"
-    # the exact-order engine alone (no MFMA tiers) agrees on the same rows
-    monkeypatch.setenv("VI_NO_MFMA", "1")
-    lab2 = torch.empty(rows.size, dtype=torch.int32, device=dev)
-    Xs = torch.from_numpy(Xh).to(dev)
-    N.check(N.lib().vi_assign_device(0, Xs.data_ptr(), rows.size, d, Cn.data_ptr(), k, 42, N.VI_ASSIGN_EXACT,
-                                     lab2.data_ptr(), None))
-    assert (lab2.cpu().numpy().astype(np.uint64) == want).all()
+    hip = Hip()
+    try:
+        Xd, Cd = hip.upload(X), hip.upload(Cn)
+        lab, amb = hip.alloc(n * 4), hip.alloc(n * 4)
+        st = N.AssignStats()
+        st.ambiguous_rows_dev = amb
+        st.ambiguous_cap = n
+        N.check(N.lib().vi_assign_device(0, Xd, n, d, Cd, k, 42, N.VI_ASSIGN_EXACT, lab, C.byref(st)))
+        assert st.used_mfma == 1
+        n_amb = int(st.tier1_rows)
+        assert 0 < n_amb < n // 10 and int(st.ambiguous_rows) <= n_amb
+        rows_amb = hip.download(amb, (n,), np.uint32)[:n_amb].astype(np.int64)
+        assert (rows_amb < n).all() and np.unique(rows_amb).size == n_amb
+        rows = np.unique(np.concatenate([rows_amb, rng.choice(n, 20_000, replace=False), [0, n - 1]]))
+        Xh = np.ascontiguousarray(X[rows])
+        want = O.assign(Xh, Cn, mode="brute")
+        got = hip.download(lab, (n,), np.uint32)[rows].astype(np.uint64)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (f"{bad.size} of {rows.size} labels differ (first row {rows[bad[0]]}: "
+                               f"{got[bad[0]]} vs {want[bad[0]]}); tiers: {n_amb} undecided by bf16x3, "
+                               f"{int(st.ambiguous_rows)} re-evaluated exactly")
+        # the exact-order engine alone (no MFMA tiers) agrees on the same rows
+        monkeypatch.setenv("VI_NO_MFMA", "1")
+        lab2 = hip.alloc(rows.size * 4)
+        N.check(N.lib().vi_assign_device(0, hip.upload(Xh), rows.size, d, Cd, k, 42, N.VI_ASSIGN_EXACT, lab2, None))
+        assert (hip.download(lab2, (rows.size,), np.uint32).astype(np.uint64) == want).all()
+    finally:
+        hip.close()

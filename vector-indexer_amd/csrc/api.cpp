@@ -9,6 +9,7 @@
 
 #include "device_index.hpp"
 #include "kmeans.hpp"
+#include "rng.hpp"
 #include "shards.hpp"
 
 namespace vi {
@@ -178,6 +179,54 @@ vi_status vi_kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k,
   opt.mode = mode;
   return vi::kmeans_parallel(X, n, d, k, max_iters, thr, seed, opt, C, labels, iters);
 }
+
+vi_status vi_kmeans_mini_batch_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
+                                      uint64_t max_iters, float thr, uint64_t seed, vi_assign_mode mode, float *C_dev,
+                                      uint32_t *labels_dev, uint64_t *iters) {
+  return vi::kmeans_mini_batch_device(device, X_dev, n, d, k, max_iters, thr, seed, mode, C_dev, labels_dev, iters);
+}
+
+vi_status vi_kmeans_parallel_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
+                                    uint64_t max_iters, float thr, uint64_t seed, vi_assign_mode mode, float *C_dev,
+                                    uint32_t *labels_dev, uint64_t *iters) {
+  return vi::kmeans_parallel_device(device, X_dev, n, d, k, max_iters, thr, seed, mode, C_dev, labels_dev, iters);
+}
+
+vi_status vi_kmeans_mini_batch_train(int32_t device, const vi_row_source *rows, uint64_t n, uint32_t d, uint64_t k,
+                                     uint64_t max_iters, float thr, uint64_t seed, float *C_dev, uint64_t *iters) {
+  if (!rows) return fail(VI_ERR_INVALID_INPUT, "null row source");
+  return vi::kmeans_mini_batch_train(device, *rows, n, d, k, max_iters, thr, seed, C_dev, iters);
+}
+
+vi_status vi_kmeans_pp_init(int32_t device, const vi_row_source *rows, uint64_t n, uint32_t d, uint64_t k, uint64_t seed,
+                            float *C_dev) {
+  if (!rows) return fail(VI_ERR_INVALID_INPUT, "null row source");
+  return vi::kmeans_pp_init_rows_entry(device, *rows, n, d, k, seed, C_dev);
+}
+
+vi_status vi_kmeans_partial_sums_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d,
+                                        const uint32_t *labels_dev, uint64_t k, float *sums_dev, uint32_t *counts_dev) {
+  return vi::kmeans_partial_sums_device(device, X_dev, n, d, labels_dev, k, sums_dev, counts_dev);
+}
+
+vi_status vi_kmeans_finish_update_device(int32_t device, const float *sums_dev, const uint32_t *counts_dev, uint64_t k,
+                                         uint32_t d, const float *C_prev_dev, float *C_new_dev, float *delta_out,
+                                         uint32_t *empty_out, uint64_t *n_empty) {
+  return vi::kmeans_finish_update_device(device, sums_dev, counts_dev, k, d, C_prev_dev, C_new_dev, delta_out, empty_out,
+                                         n_empty);
+}
+
+vi_status vi_kmeans_centroid_delta_device(int32_t device, const float *C_new_dev, const float *C_prev_dev, uint64_t k,
+                                          uint32_t d, float *delta_out) {
+  return vi::kmeans_centroid_delta(device, C_new_dev, C_prev_dev, k, d, delta_out);
+}
+
+vi_rng *vi_rng_seed_from_u64(uint64_t seed) { return reinterpret_cast<vi_rng *>(new (std::nothrow) vi::StdRng(seed)); }
+uint64_t vi_rng_gen_range(vi_rng *rng, uint64_t low, uint64_t high) {
+  if (!rng || high <= low) return low;
+  return reinterpret_cast<vi::StdRng *>(rng)->gen_range(low, high);
+}
+void vi_rng_free(vi_rng *rng) { delete reinterpret_cast<vi::StdRng *>(rng); }
 
 vi_status vi_shard_save_to(const char *shards_dir, uint64_t shard_id, uint32_t dim, uint32_t num_lists,
                            const uint64_t *centroid_ids, const float *centroid_vecs, const uint64_t *list_off,

@@ -63,10 +63,10 @@ struct SearchWorkspace {
   uint64_t c_nq = 0;                        // ... for this batch size
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
   DevBuf<uint32_t> item_list;               // list of each rank work item
-  DevBuf<uint32_t> tile_start, pair_pos;    // block records: first tile of each list; position of a pair in its list
-  DevBuf<float> gval;                       // group records: 4 smallest values per (query, probe, segment, lane half)
-  DevBuf<uint32_t> gpos;                    // ... and their positions
-  DevBuf<float> brec;                       // block records: 4 smallest values per (tile, lane half, query of the group)
+  DevBuf<uint32_t> tile_start, pair_pos;    // pair records: first record tile of each list; position of a (query, probe) pair in its list
+  DevBuf<float> gval;                       // group records: 4 smallest sub-block minima per (query, probe, segment, lane half)
+  DevBuf<uint32_t> gpos;                    // ... and where each record belongs (probe rank | segment | lane half)
+  DevBuf<float> brec;                       // pair records: the 4 sub-block minima of two blocks per (record tile, lane half, query of the group)
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

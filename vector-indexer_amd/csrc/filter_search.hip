@@ -11,30 +11,27 @@
 //                m(q,v) = ||v||^2 - 2 q.v on the matrix cores (A = 64 vectors staged in LDS, B = the group's
 //                queries in registers, accumulator initialised with ||v||^2): v_mfma_f32_32x32x16_bf16 on
 //                operands split hi + lo (hi.hi + hi.lo + lo.hi, mfma_bf16.hpp), or v_mfma_f32_32x32x2_f32.
-//                A lane owns one query and 32 of the 64 rows of every block (a "lane-block").  Per
-//                block it keeps the four smallest values b1 <= .. <= b4 of its 32 (the row index
-//                rides in the 5 low mantissa bits, so min/med3 carry it for free) and stores them
-//                as a 16-byte BLOCK RECORD; per segment it keeps the four smallest of all b1/b2
-//                with their positions, T0 <= T1 <= T2 <= T3, stored as a 32-byte GROUP RECORD when
-//                the item ends — no thresholds, no atomics, no candidate lists, nothing that can
-//                overflow.
-//   2. select    one wave per query reads its group records (~4 values per 512 scanned vectors).
+//                A lane owns one query and 32 of the 64 rows of every block: the 16 accumulator registers of each
+//                of the two 32-row tiles, a SUB-BLOCK of 16 rows.  All that is kept of a sub-block is its minimum
+//                (8 v_min3_f32): two blocks' four minima form a 16-byte PAIR RECORD, and the four smallest minima
+//                of the segment, T0 <= T1 <= T2 <= T3 (a v_med3_f32 network, no positions), a GROUP RECORD — no
+//                thresholds, no atomics, no candidate lists, no index bits stolen from the values, nothing that can
+//                overflow.  (Round 1 kept the four smallest rows of every 32 with their indices in the low mantissa
+//                bits: 226 vector instructions and 16 B per block and lane against 28 and 8 B now.)
+//   2. select    one wave per query reads its group records (4 values per 1024 scanned vectors).
 //                With m_K the K-th smallest recorded value, every vector of the true top-K has
 //                    m <= thr = m_K + 2E + 3 gamma (m_K + ||q||^2 + E)            (*)
 //                    gamma = (D+2) u'                      rounding of the reference's sequential sum
-//                    E     = e (||q||^2 + 2 max||v||^2), e = rank arithmetic + packed bits (select_common)
-//                because the K recorded vectors below m_K already bound the K-th reference distance.
-//                What a record does not list is bounded by what it does:
-//                  - values dropped from T are >= T3, so T3 <= thr => every block record of the group
-//                    is consulted;
-//                  - the rows of a block not listed in T are >= its b2, so a listed b2 <= thr => that
-//                    block record is consulted;
-//                  - the rows missing from a block record are >= its b4, so b4 <= thr => the whole
-//                    lane-block (32 vectors) is re-evaluated;
-//                  - otherwise only the listed vectors with value <= thr are.
-//                Re-evaluation = the reference's exact sequential f32 distance; the top-K of those under
-//                the reference's stable order (distance, shard visiting order, position) is the answer,
-//                bit for bit (tests/test_search_gpu.py).
+//                    E     = e (||q||^2 + 2 max||v||^2), e = rank arithmetic (select_common)
+//                because the K recorded minima below m_K belong to K different vectors, which already bound the
+//                K-th reference distance.  A vector with m <= thr sits in a sub-block whose minimum is <= thr, and a
+//                sub-block with minimum <= thr sits in a group with T0 <= thr: the pair records of exactly those
+//                groups are read, and every sub-block whose minimum is <= thr is re-evaluated as a whole — 16
+//                reference distances (exact sequential f32, src/utils.rs:28-30), four sub-blocks per wave
+//                instruction.  The top-K of those under the reference's stable order (distance, shard visiting
+//                order, position) is the answer, bit for bit (tests/test_search_gpu.py).  Groups whose T3 is below
+//                the first bound hide neighbours behind their four listed minima; their pair records tighten the
+//                bound before anything is re-evaluated.
 //
 // The coarse quantizer (ivf_index.rs:205-220) is the same computation with the centroid table as one
 // list probed by every query and K = n_probe.
@@ -69,7 +66,8 @@ constexpr int kWave = 64;
 constexpr int kGroupQ = 128;       // queries per work item: 4 waves x one MFMA column tile of 32
 constexpr uint32_t kPosBits = 26;  // candidate key = (probe rank << 26) | position in list
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
-constexpr uint32_t kB2Flag = 0x80000000u;  // record position flag: the value is a block's SECOND smallest
+// pair records of one list segment of segb blocks (every segment of a list reserves the same number)
+__host__ __device__ inline uint32_t seg_records(uint32_t segb) { return (segb + 1u) / 2u; }
 constexpr float kBig = 3.0e38f;            // norm of pad slots inside the kernel (finite: low bits are reused)
 
 __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, float *xnorm, uint32_t *xmax_bits) {
@@ -205,11 +203,11 @@ struct FilterArgs {
   uint32_t nlists, P, segb0;
   const uint32_t *qoff, *rel;  // group-record offsets (lists) ...
   uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
-  const uint32_t *tile_start;  // block records: first (128-query group, block) tile of each list
+  const uint32_t *tile_start;  // pair records: first record tile (2 * GQ records) of each list
   const uint32_t *item_list;   // list of each work item (null: binary search over item_start)
-  float4 *gval;
-  uint4 *gpos;
-  float4 *brec;
+  float4 *gval;                // group records: the four smallest sub-block minima of a (pair, segment, lane half)
+  uint32_t *gmeta;             // ... and where the record belongs: probe rank | segment << 6 | lane half << 13
+  float4 *brec;                // pair records: the sub-block minima of two blocks
   uint32_t xmode;  // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no ranking epilogue
 };
 
@@ -220,21 +218,26 @@ struct FilterArgs {
 // followed by the block's 64 squared norms.  With NBUF = 2 the next block lands in the other buffer while
 // this one is multiplied (one barrier per block); with NBUF = 1 the load is exposed and hidden by the other
 // workgroups of the CU (3 per CU instead of 2).
-// value with the element index e (0..31) in its 5 low mantissa bits: |packed - m| < 2^-18 |m|
-__device__ __forceinline__ float pack_idx(float m, uint32_t e) {
-  return __uint_as_float((__float_as_uint(m) & ~31u) | e);
+// minimum of three without the canonicalising v_max the compiler puts in front of fminf on values it cannot prove quiet
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+  float d;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
-
-// sorted insert of (v, pos) into T0 <= T1 <= T2 <= T3
-#define VI_INS(Ti, Pi)        \
-  {                           \
-    const bool c_ = v < Ti;   \
-    const float tv_ = Ti;     \
-    const uint32_t tp_ = Pi;  \
-    Ti = c_ ? v : tv_;        \
-    Pi = c_ ? pos : tp_;      \
-    v = c_ ? tv_ : v;         \
-    pos = c_ ? tp_ : pos;     \
+// the minimum of a 32x32 accumulator tile's 16 registers (8 instructions)
+__device__ __forceinline__ float tile_min(const f32x16 &a) {
+  const float m0 = min3_raw(a[0], a[1], a[2]), m1 = min3_raw(a[3], a[4], a[5]);
+  const float m2 = min3_raw(a[6], a[7], a[8]), m3 = min3_raw(a[9], a[10], a[11]);
+  const float m4 = min3_raw(a[12], a[13], a[14]);
+  return min3_raw(min3_raw(m0, m1, m2), min3_raw(m3, m4, a[15]), m0);
+}
+// v into the sorted four smallest T0 <= T1 <= T2 <= T3 (v_med3_f32 takes its operands as they are)
+#define VI_TOP4(v)                             \
+  {                                            \
+    T3 = __builtin_amdgcn_fmed3f(T2, T3, v);   \
+    T2 = __builtin_amdgcn_fmed3f(T1, T2, v);   \
+    T1 = __builtin_amdgcn_fmed3f(T0, T1, v);   \
+    T0 = min3_raw(T0, v, v);                   \
   }
 
 // one block image -> LDS: all of it, or (RANK 2) only its hi planes: pieces (chunk c, plane 0, half h) = 4c + h
@@ -341,17 +344,19 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
     }
   }
 
-  float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
-  uint32_t P0 = kNoPos, P1 = kNoPos, P2 = kNoPos;  // (T3 only guards: its position is never needed)
-  // block records are item-major — [tile = (query group, block)][lane half][query of the group] — so that a
-  // wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host)
-  const uint32_t bi = (a.tile_start[l] + chunk * nblk) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
+  float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;  // four smallest sub-block minima of the segment
+  float4 w = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);    // the pair record being filled
+  // pair records are item-major — [record tile = (query group, segment, pair of blocks)][lane half][query of the
+  // group] — so that a wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host);
+  // tile_start counts the record tiles of the lists before this one: chunks x segments x seg_records
+  const uint32_t bi = (a.tile_start[l] + (chunk * nseg + seg) * seg_records(segb)) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
 
   tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
     const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
+    bool stored = false;  // this lane stored a pair record in this iteration
     const float *s_tile = s_tiles[NBUF == 2 ? ((blk - b0) & 1u) : 0];
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
@@ -439,38 +444,14 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
         }
       }
       if (!(a.xmode & 2u)) {
-        // the four smallest of this lane's 32 values, element index in the low bits
-        float bm1 = INFINITY, bm2 = INFINITY, bm3 = INFINITY, bm4 = INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = pack_idx(acc0[r], (uint32_t)r);
-          bm4 = __builtin_amdgcn_fmed3f(bm3, bm4, p);
-          bm3 = __builtin_amdgcn_fmed3f(bm2, bm3, p);
-          bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
-          bm1 = fminf(bm1, p);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = pack_idx(acc1[r], 16u + (uint32_t)r);
-          bm4 = __builtin_amdgcn_fmed3f(bm3, bm4, p);
-          bm3 = __builtin_amdgcn_fmed3f(bm2, bm3, p);
-          bm2 = __builtin_amdgcn_fmed3f(bm1, bm2, p);
-          bm1 = fminf(bm1, p);
-        }
-        if (qlive && !(a.xmode & 8u)) a.brec[(size_t)bi + (2u * GQ) * blk] = make_float4(bm1, bm2, bm3, bm4);
-        // element e <-> vector 32*(e>>4) + (r&3) + 8*(r>>2) + 4*h of the block, r = e & 15
-        const uint32_t pb = blk * kWave + 4u * (uint32_t)h;
-        if (!(a.xmode & 16u)) {
-          const uint32_t e = __float_as_uint(bm1) & 31u, r = e & 15u;
-          float v = bm1;
-          uint32_t pos = pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2);
-          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) T3 = fminf(T3, v);
-        }
-        {
-          const uint32_t e = __float_as_uint(bm2) & 31u, r = e & 15u;
-          float v = bm2;
-          uint32_t pos = (pb + 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2)) | kB2Flag;
-          VI_INS(T0, P0) VI_INS(T1, P1) VI_INS(T2, P2) T3 = fminf(T3, v);
+        // all that is kept of the two 16-row sub-blocks: their minima
+        const float m0 = tile_min(acc0), m1 = tile_min(acc1);
+        VI_TOP4(m0) VI_TOP4(m1)
+        if (((blk - b0) & 1u) == 0u) { w.x = m0; w.y = m1; w.z = INFINITY; w.w = INFINITY; }
+        else { w.z = m0; w.w = m1; }
+        if (((blk - b0) & 1u) != 0u || blk + 1 == b1) {  // the pair is complete (wave-uniform)
+          stored = qlive && !(a.xmode & 8u);
+          if (stored) a.brec[(size_t)bi + (2u * GQ) * ((blk - b0) >> 1)] = w;
         }
       }
     }
@@ -483,10 +464,11 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
       __syncthreads();  // next tile visible
     } else {
       // The next tile's LDS-DMA was issued before this block's MFMAs; the only younger vector-memory operation
-      // is this wave's block-record store (vmcnt counts loads, stores and LDS-DMA together, in issue order).
+      // is this wave's pair-record store, if it made one (vmcnt counts loads, stores and LDS-DMA together, in issue order).
       // Waiting for all but that store keeps the store's latency off the critical path; __syncthreads() would
       // insert vmcnt(0), hence the raw barrier (LDS reads of this tile are complete: lgkmcnt(0)).
-      if (wave_live && !(a.xmode & 10u)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // (a record store is issued iff some lane of the wave stores: the ballot is the wave-uniform form of that)
+      if (__ballot(stored) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // next tile visible; this tile free to be overwritten
@@ -495,8 +477,7 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   if (qlive) {
     const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
     a.gval[gi] = make_float4(T0, T1, T2, T3);
-    // the 4th position is never needed (T3 only guards): its slot carries where the record belongs
-    a.gpos[gi] = make_uint4(P0, P1, P2, (slot - qid * a.P) | (seg << 6) | ((uint32_t)h << 13));
+    a.gmeta[gi] = (slot - qid * a.P) | (seg << 6) | ((uint32_t)h << 13);  // where the record belongs
   }
 }
 
@@ -508,17 +489,18 @@ struct SelectCommon {
   uint32_t dim, dq;
   const float4 *blocks;
   const float4 *gval;
-  const uint4 *gpos;
+  const uint32_t *gmeta;
   const float4 *brec;
   float gamma, e_scale, xmax2;
-  uint32_t gq;  // queries per rank work item (block-record tiles hold 2 * gq records)
-  unsigned long long *dbg;  // [6] exact re-evaluations, [7] block records consulted
+  uint32_t gq;  // queries per rank work item (a record tile holds 2 * gq pair records)
+  unsigned long long *dbg;  // [6] exact re-evaluations, [7] groups whose pair records were read, [8..] see select_body
 };
 
 // the query's probes, one per lane r < P
 struct ProbeRegs {
   uint32_t rel, ng;   // first group record (relative to the query's) / number of group records of the probe
-  uint32_t boff;      // block record of (block 0, lane half 0) of the probe; + 2*gq per block, + gq for half 1
+  uint32_t boff;      // pair record of (segment 0, pair 0, lane half 0) of the probe; + 2*gq per pair
+                      // (pair p of segment s = s * seg_records(segb) + p), + gq for half 1
   uint32_t len, fb;   // list length and first block
   uint32_t segb;      // blocks per segment
   uint32_t g;         // candidate-order rank (shard visiting order)
@@ -564,23 +546,21 @@ __device__ __attribute__((noinline)) WaveTopK exact_batch_fn(WaveTopK sel, const
   return sel;
 }
 
-// vector (within its 64-vector block) of element e of a lane-block: lane half hh owns rows (r&3)+8(r>>2)+4hh of
-// the 32-row tile e>>4, r = e & 15 (MFMA 32x32 accumulator layout)
-__device__ __forceinline__ uint32_t element_vector(uint32_t e, uint32_t hh) {
-  const uint32_t r = e & 15u;
-  return 32u * (e >> 4) + (r & 3u) + 8u * (r >> 2) + 4u * hh;
+// vector (within its 64-vector block) of row e (0..15) of sub-block (tile t, lane half hh): the 32x32 accumulator of
+// tile t holds rows (e&3) + 8(e>>2) + 4hh of the tile in the 16 registers of a lane of half hh
+__device__ __forceinline__ uint32_t subblock_vector(uint32_t e, uint32_t t, uint32_t hh) {
+  return 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * hh;
 }
 
-constexpr uint32_t kPickCap = 256;     // listed vectors waiting for their exact distance (per wave)
-constexpr uint32_t kConsultCap = 128;  // block records waiting to be consulted (per wave)
-constexpr uint32_t kBlkBits = 20;      // consult key = (probe rank << 21) | (block << 1) | lane half
+constexpr uint32_t kPickCap = 256;     // sub-blocks waiting for their 16 exact distances (per wave)
+constexpr uint32_t kSubBits = 21;      // request key = (probe rank << 22) | (sub-block of the list << 1) | lane half
 constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/half) kept in LDS per wave
 
 // One wave: top-K of query q under (exact distance, (g << 26) | position) from its G group records at gbase.
 // Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
-                                            const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick,
-                                            uint32_t *consult, float4 *tcache, uint32_t *lcache, WaveTopK &sel) {
+                                            const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick, float4 *tcache,
+                                            uint32_t *lcache, WaveTopK &sel) {
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -600,9 +580,8 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const float scale = fmaxf(mk + qn, 0.0f) + E;
     return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
   };
-  uint32_t npick = 0, ncons = 0, n_exact = 0, n_consult = 0, n_full = 0, n_b2 = 0, n_whole = 0;
+  uint32_t npick = 0, n_exact = 0, n_scanned = 0, n_full = 0, n_sub = 0;
   WaveTopK s1;
-  // block records waiting in `consult`; mode 0 = their values refine the threshold, mode 1 = stage 2
   float thr = INFINITY;
   sel.init();
   const float *qrow = c.Q + (size_t)q * c.dim;
@@ -615,86 +594,79 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     sel = exact_batch_fn(sel, qrow, c.blocks + ((size_t)(fb + (live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave),
                          c.dim, live, (g << kPosBits) | pos, (int)K);
   };
+  // sub-blocks waiting in `pick`: four per round, 16 lanes (= the 16 rows of the sub-block) each
   auto drain_pick = [&]() {
     while (npick > 0) {
-      const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
+      const uint32_t cnt = npick >= 4u ? 4u : npick;
       npick -= cnt;
-      const bool live = (uint32_t)lane < cnt;
-      const uint32_t ck = live ? pick[npick + lane] : 0u;
-      exact_offer(live, ck >> kPosBits, ck & kPosMask);
+      const uint32_t rq = (uint32_t)lane >> 4;
+      const bool live = rq < cnt;
+      const uint32_t ck = live ? pick[npick + rq] : 0u;
+      const uint32_t r = ck >> (kSubBits + 1), sub = (ck >> 1) & ((1u << kSubBits) - 1u), hh = ck & 1u;
+      exact_offer(live, r, (sub >> 1) * kWave + subblock_vector((uint32_t)lane & 15u, sub & 1u, hh));
     }
   };
-  auto push_single = [&](bool want, uint32_t r, uint32_t pos) {  // every lane calls
+  auto push_sub = [&](bool want, uint32_t r, uint32_t sub, uint32_t hh) {  // every lane calls
     const uint64_t m = __ballot(want);
     if (!m) return;
     const uint32_t cnt = (uint32_t)__popcll(m);
+    n_sub += cnt;
     if (npick + cnt > kPickCap) drain_pick();
-    if (want) pick[npick + (uint32_t)__popcll(m & below)] = (r << kPosBits) | pos;
+    if (want) pick[npick + (uint32_t)__popcll(m & below)] = (r << (kSubBits + 1)) | (sub << 1) | hh;
     npick += cnt;
     lds_sync();
   };
-  // a whole lane-block: 32 lanes, one vector each (requests are rare: one at a time)
-  const int sub = lane & 31;
-  auto lane_blocks = [&](bool want, uint32_t r, uint32_t blk, uint32_t hh) {
+  // The pair records of the groups flagged `want`, four groups per round (16 lanes x one pair record = the 64
+  // sub-block minima of a 32-block segment half).  mode 0: the minima go to the running top-K of rank values (s1);
+  // mode 1: every sub-block whose minimum is at or below thr is queued for exact evaluation.
+  auto scan_groups = [&](bool want, uint32_t r, uint32_t seg, uint32_t hh, int mode) {
     uint64_t m = __ballot(want);
+    const uint32_t slot = (uint32_t)lane >> 4, pi = (uint32_t)lane & 15u;
     while (m) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const uint32_t rr = readlane_u(r, src), bb = readlane_u(blk, src), h2 = readlane_u(hh, src);
-      exact_offer(lane < 32, rr, bb * kWave + element_vector((uint32_t)sub, h2));
-    }
-  };
-  auto drain_consult = [&](int mode) {
-    while (ncons > 0) {
-      const uint32_t cnt = ncons >= (uint32_t)kWave ? (uint32_t)kWave : ncons;
-      ncons -= cnt;
-      const bool live = (uint32_t)lane < cnt;
-      const uint32_t ck = live ? consult[ncons + lane] : 0u;
-      const uint32_t r = ck >> (kBlkBits + 1), blk = (ck >> 1) & ((1u << kBlkBits) - 1u), hh = ck & 1u;
-      const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)r);
-      float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-      if (live) B = c.brec[(size_t)boff + 2u * c.gq * blk + c.gq * hh];
-      if (mode == 0) {
-        s1 = offer_bulk_fn(s1, B.x, live ? 0u : kNoPos, (int)K);
-        s1 = offer_bulk_fn(s1, B.y, live ? 1u : kNoPos, (int)K);
-        s1 = offer_bulk_fn(s1, B.z, live ? 2u : kNoPos, (int)K);
-        s1 = offer_bulk_fn(s1, B.w, live ? 3u : kNoPos, (int)K);
-      } else {
-        n_consult += cnt;
-        const bool whole = live && (B.w <= thr || distrust);  // rows missing from the record are only known to be >= b4
-        n_whole += (uint32_t)__popcll(__ballot(whole));
-        const float bv[3] = {B.x, B.y, B.z};
+      int src = 0;
+      uint32_t taken = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          push_single(live && !whole && bv[i] <= thr, r, blk * kWave + element_vector(__float_as_uint(bv[i]) & 31u, hh));
-        lane_blocks(whole, r, blk, hh);
+      for (uint32_t i = 0; i < 4; ++i)
+        if (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1ull;
+          if (slot == i) src = b;
+          ++taken;
+        }
+      const bool mine = slot < taken;
+      n_scanned += taken;
+      const uint32_t rr = (uint32_t)__shfl((int)r, src), sg = (uint32_t)__shfl((int)seg, src);
+      const uint32_t h2 = (uint32_t)__shfl((int)hh, src);
+      const uint32_t segb = (uint32_t)__shfl((int)pr.segb, (int)rr), ln = (uint32_t)__shfl((int)pr.len, (int)rr);
+      const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)rr);
+      const uint32_t nblk = (ln + kWave - 1) / kWave;
+      const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
+      const uint32_t npairs = (mine && be > bs) ? (be - bs + 1u) / 2u : 0u;
+      uint32_t mx = npairs;  // wave maximum: segments of very long lists hold more than 16 pairs
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+      for (uint32_t p0 = 0; p0 < mx; p0 += 16u) {
+        const uint32_t p = p0 + pi;
+        const bool live = p < npairs;
+        float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+        if (live) B = c.brec[(size_t)boff + 2u * c.gq * (sg * seg_records(segb) + p) + c.gq * h2];
+        if (mode == 0) {
+          s1 = offer_bulk_fn(s1, B.x, live ? 0u : kNoPos, (int)K);
+          s1 = offer_bulk_fn(s1, B.y, live ? 1u : kNoPos, (int)K);
+          s1 = offer_bulk_fn(s1, B.z, live ? 2u : kNoPos, (int)K);
+          s1 = offer_bulk_fn(s1, B.w, live ? 3u : kNoPos, (int)K);
+        } else {
+          const float bv[4] = {B.x, B.y, B.z, B.w};
+          const uint32_t blk0 = bs + 2u * p;
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j)  // (!(v > thr): a NaN minimum is expanded, never skipped)
+            push_sub(live && blk0 + (j >> 1) < be && !(bv[j] > thr), rr, (blk0 + (j >> 1)) * 2u + (j & 1u), h2);
+        }
       }
     }
   };
-  auto push_consult = [&](bool want, uint32_t r, uint32_t blk, uint32_t hh, int mode) {  // every lane calls
-    const uint64_t m = __ballot(want);
-    if (!m) return;
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    if (ncons + cnt > kConsultCap) drain_consult(mode);
-    if (want) consult[ncons + (uint32_t)__popcll(m & below)] = (r << (kBlkBits + 1)) | (blk << 1) | hh;
-    ncons += cnt;
-    lds_sync();
-  };
-  // every block record of the groups flagged `full`
-  auto consult_groups = [&](bool full, uint32_t r, uint32_t seg, uint32_t hh, int mode) {
-    uint64_t m = __ballot(full);
-    while (m) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1ull;
-      const uint32_t rr = readlane_u(r, src), sg = readlane_u(seg, src), h2 = readlane_u(hh, src);
-      const uint32_t segb = readlane_u(pr.segb, (int)rr), ln = readlane_u(pr.len, (int)rr);
-      const uint32_t nblk = (ln + kWave - 1) / kWave;
-      const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
-      for (uint32_t b = bs; b < be; b += kWave) push_consult(b + lane < be, rr, b + lane, h2, mode);
-    }
-  };
 
-  // ---- stage 0: the first 256 group records go to LDS in one round of loads (the three passes below would
+  // ---- stage 0: the first 256 group records go to LDS in one round of loads (the passes below would
   //      otherwise each pay the global-memory latency per 64 groups) ----
   {
     float4 t4[kCacheG / kWave];
@@ -709,7 +681,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
       const uint32_t gidx = ch * kWave + lane;
       l4[ch] = 0u;
-      if (gidx < G) l4[ch] = c.gpos[gbase + gidx].w;  // probe rank | segment << 6 | lane half << 13
+      if (gidx < G) l4[ch] = c.gmeta[gbase + gidx];  // probe rank | segment << 6 | lane half << 13
     }
 #pragma unroll
     for (uint32_t ch = 0; ch < kCacheG / kWave; ++ch) {
@@ -728,7 +700,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   };
   auto group_place = [&](uint32_t gidx, bool live, uint32_t &r, uint32_t &seg, uint32_t &hh) {
     uint32_t L = 0u;
-    if (live) L = gidx < kCacheG ? lcache[gidx] : c.gpos[gbase + gidx].w;
+    if (live) L = gidx < kCacheG ? lcache[gidx] : c.gmeta[gbase + gidx];
     r = L & 63u; seg = (L >> 6) & 127u; hh = L >> 13;
   };
   // ---- stage 1a: threshold (*) from the K-th smallest value of the group records (key = 4*group + slot);
@@ -756,11 +728,11 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       any_full = any_full || __ballot(gidx < G && T.w <= thr) != 0ull;  // (distrust: thr = inf, stage 1b is moot)
     }
   }
-  // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed values and leave the bound
-  //      loose; the block records of those groups list 4 values per 32 vectors.  Their values REPLACE the
+  // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed minima and leave the bound
+  //      loose; the pair records of those groups list every sub-block minimum.  Their values REPLACE the
   //      group's own (which are among them, so they must not be counted twice): drop the group's entries from
-  //      the running top-K, then offer its block records ----
-  if (any_full) {
+  //      the running top-K, then offer its pair records ----
+  if (any_full && !distrust) {
     {
       const bool mine = s1.p != kNoPos && (uint32_t)lane < K;  // entries beyond the K-th are not needed
       const uint32_t g = mine ? (s1.p >> 2) : 0u;
@@ -792,58 +764,28 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       const bool live = gidx < G;
       uint32_t r, seg, hh;
       group_place(gidx, live, r, seg, hh);
-      consult_groups(live && group_values(gidx, live).w <= thr, r, seg, hh, 0);
+      scan_groups(live && group_values(gidx, live).w <= thr, r, seg, hh, 0);
     }
-    drain_consult(0);
     thr = fminf(thr, threshold_of(readlane_f(s1.d, (int)K - 1)));
   }
-  // ---- stage 2: exact re-evaluation of what can be at or below thr ----
+  // ---- stage 2: exact re-evaluation of every sub-block whose minimum is at or below thr; such a sub-block sits in a
+  //      group whose smallest minimum is at or below thr ----
   for (uint32_t gb = 0; gb < G; gb += kWave) {
     const uint32_t gidx = gb + lane;
     const bool live = gidx < G;
     uint32_t r, seg, hh;
     group_place(gidx, live, r, seg, hh);
-    const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     const float4 T = group_values(gidx, live);
-    const bool full = live && (T.w <= thr || distrust);
-    n_full += (uint32_t)__popcll(__ballot(full));
-    // positions are only needed by chunks that list something at or below thr
-    uint4 Pp = make_uint4(kNoPos, kNoPos, kNoPos, kNoPos);
-    if (live && !full && T.x <= thr) Pp = c.gpos[gbase + gidx];
-    const float tv[3] = {T.x, T.y, T.z};
-    const uint32_t tp[3] = {Pp.x, Pp.y, Pp.z};
-    bool pass[3], is2[3];
-    uint32_t blk[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      pass[i] = live && !full && tv[i] <= thr && tp[i] != kNoPos && (tp[i] & kPosMask) < len;
-      is2[i] = (tp[i] & kB2Flag) != 0u;
-      blk[i] = (tp[i] & kPosMask) >> 6;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      // a listed smallest-of-its-block is evaluated directly unless that block's record is consulted anyway
-      bool single = pass[i] && !is2[i];
-#pragma unroll
-      for (int jx = 0; jx < 3; ++jx)
-        if (jx != i && pass[jx] && is2[jx] && blk[jx] == blk[i]) single = false;
-      push_single(single, r, tp[i] & kPosMask);
-      // a listed second-smallest says nothing about its block's other rows: consult the block record
-      n_b2 += (uint32_t)__popcll(__ballot(pass[i] && is2[i]));
-      push_consult(pass[i] && is2[i], r, blk[i], hh, 1);
-    }
-    // the fourth-smallest listed value is at or below thr: consult every block record of the group
-    consult_groups(full, r, seg, hh, 1);
+    n_full += (uint32_t)__popcll(__ballot(live && T.w <= thr));
+    scan_groups(live && !(T.x > thr), r, seg, hh, 1);
   }
-  drain_consult(1);
   drain_pick();
   if (c.dbg && lane == 0) {
     atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
-    atomicAdd(&c.dbg[7], (unsigned long long)n_consult);
+    atomicAdd(&c.dbg[7], (unsigned long long)n_scanned);
     atomicAdd(&c.dbg[8], (unsigned long long)(any_full ? 1u : 0u));
     atomicAdd(&c.dbg[9], (unsigned long long)n_full);
-    atomicAdd(&c.dbg[10], (unsigned long long)n_b2);
-    atomicAdd(&c.dbg[11], (unsigned long long)n_whole);
+    atomicAdd(&c.dbg[10], (unsigned long long)n_sub);
   }
 }
 
@@ -861,7 +803,7 @@ struct SelectArgs {
 
 // one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap], s_lcache[4][kCacheG];
+  __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
@@ -877,12 +819,13 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
       pr.len = a.list_len[mylist];
       pr.fb = a.first_block[mylist];
       const uint32_t pp = a.pair_pos[s];  // where the pair sits among the pairs of its list
-      pr.boff = (a.tile_start[mylist] + (pp / a.c.gq) * ((pr.len + 63u) / 64u)) * (2u * a.c.gq) + (pp % a.c.gq);
-      pr.ng = 2u * list_segments(pr.len, a.segb0, &pr.segb);
+      const uint32_t nseg = list_segments(pr.len, a.segb0, &pr.segb);
+      pr.ng = 2u * nseg;
+      pr.boff = (a.tile_start[mylist] + (pp / a.c.gq) * nseg * seg_records(pr.segb)) * (2u * a.c.gq) + (pp % a.c.gq);
     }
   }
   WaveTopK sel;
-  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
+  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
               s_lcache[wave], sel);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
   const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
@@ -925,7 +868,7 @@ struct CoarseSelectArgs {
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
 // sort, ivf_index.rs:205-220), then shard visiting order + histogram as in coarse_merge_kernel
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap], s_consult[4][kConsultCap], s_lcache[4][kCacheG];
+  __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
@@ -933,10 +876,10 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   ProbeRegs pr{0u, 0u, 0u, 0u, 0u, 1u, 0u};
   if (lane == 0) {
     pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb;
-    pr.boff = (q / a.c.gq) * ((a.nlists + 63u) / 64u) * (2u * a.c.gq) + (q % a.c.gq);  // pairs = iota: the query's own position
+    pr.boff = (q / a.c.gq) * (a.recs / 2u) * seg_records(a.segb) * (2u * a.c.gq) + (q % a.c.gq);  // pairs = iota: the query's own position
   }
   WaveTopK sel;
-  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_consult[wave], s_tcache[wave],
+  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
               s_lcache[wave], sel);
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
@@ -1020,16 +963,15 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   const double u = 1.01 * std::ldexp(1.0, -24);
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
-  c.gval = (const float4 *)ix.ws.gval.p; c.gpos = (const uint4 *)ix.ws.gpos.p;
+  c.gval = (const float4 *)ix.ws.gval.p; c.gmeta = (const uint32_t *)ix.ws.gpos.p;
   c.brec = (const float4 *)ix.ws.brec.p;
   c.gamma = (float)((ix.dim + 2.0) * u);
   // |ranked value - (||v||^2 - 2 q.v)| <= e_scale (||q||^2 + 2 max||v||^2):
   //   f32 MFMA : (D+2) u'  accumulation of D products + the norm
   //   bf16 x 3 : 3 * 2^-18 for the dropped lo.lo product and the two split residuals, and (3D+2) * 2u' for the f32
   //              accumulation of 3D exact bf16 products (2u': also covers an accumulator that truncates)
-  //   + 2^-18 for the 5 mantissa bits the rank kernel reuses as an index
   const double acc = rank_bf16() ? (3.0 * ix.dim + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (ix.dim + 2.0) * u;
-  c.e_scale = (float)(acc + 1.01 * std::ldexp(1.0, -18));
+  c.e_scale = (float)acc;
   c.xmax2 = xmax2;
   c.gq = gq;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
@@ -1145,8 +1087,8 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.c_item.reserve(2));
   VI_TRY(ws.c_pairs.reserve(nq));
   VI_TRY(ws.gval.reserve(nq * recs * 4));
-  VI_TRY(ws.gpos.reserve(nq * recs * 4));
-  VI_TRY(ws.brec.reserve((uint64_t)ngroups * ix.centroids.nblocks * 256 * 4));
+  VI_TRY(ws.gpos.reserve(nq * recs));
+  VI_TRY(ws.brec.reserve((uint64_t)ngroups * nseg * seg_records(segb) * 256 * 4));
   VI_TRY(ws.stats.reserve(16));
   if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
     VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
@@ -1164,7 +1106,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
-    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
+    a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
@@ -1246,10 +1188,10 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];
-  const uint64_t nrec = hstats[4], nbrec = hstats[3] * 2 * gq;  // block records: 2 x gq per (query group, block) tile
+  const uint64_t nrec = hstats[4], nbrec = hstats[5] * 2 * gq;  // pair records: 2 x gq per (query group, segment, 2 blocks)
   if (nrec >= (1ull << 31) || nbrec >= (1ull << 32)) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
-  VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec) * 4));
+  VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec)));
   VI_TRY(ws.brec.reserve(std::max<uint64_t>(1, nbrec) * 4));
   if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
   // ---- 3. rank on the matrix cores ----
@@ -1269,7 +1211,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       VI_HIP(hipGetLastError());
     }
     a.item_list = ws.item_list.p;
-    a.gval = (float4 *)ws.gval.p; a.gpos = (uint4 *)ws.gpos.p; a.brec = (float4 *)ws.brec.p;
+    a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
     const int rank_mode = rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0;
     stt.rank_mode = (uint64_t)rank_mode + 1;
@@ -1293,9 +1235,9 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     VI_HIP(hipStreamSynchronize(st));
     stt.filter_rechecked = dbg[6]; stt.filter_accepted = dbg[7];
     if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
-      fprintf(stderr, "select stats: exact %llu consult %llu queries_with_full_group %llu full_groups %llu listed_b2 %llu whole_lane_blocks %llu\n",
+      fprintf(stderr, "select stats: exact %llu groups_scanned %llu queries_with_full_group %llu full_groups %llu sub_blocks %llu\n",
               (unsigned long long)dbg[6], (unsigned long long)dbg[7], (unsigned long long)dbg[8], (unsigned long long)dbg[9],
-              (unsigned long long)dbg[10], (unsigned long long)dbg[11]);
+              (unsigned long long)dbg[10]);
   }
   return VI_OK;
 }

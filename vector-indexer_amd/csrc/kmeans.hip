@@ -179,6 +179,52 @@ void group_by_label(const uint32_t *labels, uint64_t n, uint64_t k, std::vector<
 }
 
 // ------------------------------------------------------------------------------------------
+// Where the training loops get data rows from.  k-means++ seeding, the mini-batches and the empty-cluster re-seeds
+// touch only a few rows, named by the rand stream: 50 000 + k + iterations x (batch + empty clusters).  Reading them
+// through this interface is what lets the same loop run on one GPU (rows gathered from resident X) and on data
+// SHARDED over the GPUs of a node (rows exchanged by the caller's collective, vi_row_source), where only the final
+// assignment of all points — the part that is O(N k D) — stays local to every rank.
+// ------------------------------------------------------------------------------------------
+struct RowSource {
+  virtual ~RowSource() = default;
+  // out_dev[i, :] = data row rows[i]; complete when the call returns or ordered on `st`
+  virtual vi_status fetch(const uint32_t *rows, uint64_t n, float *out_dev, hipStream_t st) = 0;
+  // rows 0 .. m-1 as one device matrix if they are resident that way (else nullptr: fetch them)
+  virtual const float *head(uint64_t /*m*/) { return nullptr; }
+};
+
+struct DeviceRows : RowSource {
+  const float *X;
+  uint32_t d;
+  DevBuf<uint32_t> idx;
+  DeviceRows(const float *x, uint32_t dim) : X(x), d(dim) {}
+  vi_status fetch(const uint32_t *rows, uint64_t n, float *out_dev, hipStream_t st) override {
+    if (n == 0) return VI_OK;
+    VI_TRY(idx.reserve(n));
+    VI_HIP(hipMemcpyAsync(idx.p, rows, n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)n), dim3(64), 0, st, X, idx.p, (uint32_t)n, d, out_dev);
+    VI_HIP(hipGetLastError());
+    VI_HIP(hipStreamSynchronize(st));  // `rows` is the caller's host memory
+    return VI_OK;
+  }
+  const float *head(uint64_t) override { return X; }
+};
+
+struct CallbackRows : RowSource {
+  vi_row_source cb;
+  std::vector<uint64_t> rows64;
+  explicit CallbackRows(const vi_row_source &c) : cb(c) {}
+  vi_status fetch(const uint32_t *rows, uint64_t n, float *out_dev, hipStream_t st) override {
+    if (n == 0) return VI_OK;
+    rows64.assign(rows, rows + n);
+    VI_HIP(hipStreamSynchronize(st));  // out_dev may still be read by work queued on our stream
+    const int rc = cb.fetch_rows(cb.ctx, rows64.data(), n, out_dev);
+    if (rc != 0) return fail(VI_ERR_OTHER, "vi_row_source.fetch_rows failed with %d", rc);
+    return VI_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // assign_points_brute_force on device-resident points (exact, LANES order)
 // ------------------------------------------------------------------------------------------
 struct BruteWs {
@@ -331,13 +377,14 @@ vi_status assign_device(Ctx &cx, const float *Xd, uint64_t n, const float *Cd, u
 // ------------------------------------------------------------------------------------------
 // kmeans_plus_plus_init (kmeans.rs:154-310): distances on the GPU, sampling decisions on host
 // ------------------------------------------------------------------------------------------
-vi_status kmeans_pp_init_device(Ctx &cx, const float *Xd, uint64_t n, uint32_t d, uint64_t k, uint64_t seed,
-                                float *Cd) {
+// The rows this touches are known from (n, seed) alone: the first centroid's row, the rows 0..m-1 that are measured
+// (m = min(n, 50 000): kmeans.rs:268,435 measures data rows 0..m, not the sampled rows) and the m candidate rows the
+// draws map to (sample_indices, :287-288; the identity when n <= 50 000).
+vi_status kmeans_pp_init_rows(Ctx &cx, RowSource &src, uint64_t n, uint32_t d, uint64_t k, uint64_t seed, float *Cd) {
   const uint64_t sample_threshold = 50000;
   StdRng rng(seed);
   const uint64_t actual_k = std::min(k, n);
-  std::vector<uint32_t> crow(k, 0);  // every initial centroid is a copy of some data row
-  crow[0] = (uint32_t)rng.gen_range(0, n);
+  const uint32_t row0 = (uint32_t)rng.gen_range(0, n);
   const bool sampled = n > sample_threshold;
   std::vector<uint32_t> sample_idx;
   uint64_t m = n;
@@ -347,6 +394,26 @@ vi_status kmeans_pp_init_device(Ctx &cx, const float *Xd, uint64_t n, uint32_t d
     rng.shuffle(sample_idx.data(), n);
     m = std::min(sample_threshold, n);
   }
+  // cand: row 0 = the first centroid's data row, rows 1..m = the candidates of the draws
+  DevBuf<float> cand, headbuf;
+  VI_TRY(cand.reserve((m + 1) * d));
+  const float *head = src.head(m);
+  {
+    std::vector<uint32_t> rows(m + 1);
+    rows[0] = row0;
+    for (uint64_t s = 0; s < m; ++s) rows[s + 1] = sampled ? sample_idx[s] : (uint32_t)s;
+    VI_TRY(src.fetch(rows.data(), m + 1, cand.p, cx.st));
+    if (!head) {
+      if (!sampled) head = cand.p + d;  // the candidates ARE rows 0..m-1
+      else {
+        for (uint64_t s = 0; s < m; ++s) rows[s] = (uint32_t)s;
+        VI_TRY(headbuf.reserve(m * d));
+        VI_TRY(src.fetch(rows.data(), m, headbuf.p, cx.st));
+        head = headbuf.p;
+      }
+    }
+  }
+  std::vector<uint32_t> csel(k, 0);  // every initial centroid is a copy of a row of `cand`
   DevBuf<float> min_d;
   VI_TRY(min_d.reserve(m));
   std::vector<float> h_min(m, INFINITY), w(m), cum(m);
@@ -355,9 +422,8 @@ vi_status kmeans_pp_init_device(Ctx &cx, const float *Xd, uint64_t n, uint32_t d
   VI_HIP(hipHostMalloc((void **)&pinned, std::max<uint64_t>(m, 1) * sizeof(float)));
   vi_status rc = VI_OK;
   for (uint64_t i = 1; i < actual_k && rc == VI_OK; ++i) {
-    // NB (kmeans.rs:268,435): the sampled variant measures data rows 0..m, not the sampled rows
-    hipLaunchKernelGGL(min_dist_update_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, cx.st, Xd,
-                       (uint32_t)m, d, Xd + (size_t)crow[i - 1] * d, min_d.p);
+    hipLaunchKernelGGL(min_dist_update_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, cx.st, head,
+                       (uint32_t)m, d, cand.p + (size_t)csel[i - 1] * d, min_d.p);
     if (hipMemcpyAsync(pinned, min_d.p, m * 4, hipMemcpyDeviceToHost, cx.st) != hipSuccess ||
         hipStreamSynchronize(cx.st) != hipSuccess) {
       rc = fail(VI_ERR_DEVICE, "k-means++ distance pass failed: %s", hipGetErrorString(hipGetLastError()));
@@ -365,35 +431,35 @@ vi_status kmeans_pp_init_device(Ctx &cx, const float *Xd, uint64_t n, uint32_t d
     }
     float total = 0.0f;
     for (uint64_t j = 0; j < m; ++j) { w[j] = pinned[j] * pinned[j]; total += w[j]; }  // :190,193 (dist^4, sequential)
-    if (total == 0.0f) {
-      crow[i] = crow[rng.gen_range(0, i)];
-    } else {
-      const uint64_t s = rng.weighted_index(w.data(), m, cum.data());
-      crow[i] = sampled ? sample_idx[s] : (uint32_t)s;
-    }
+    if (total == 0.0f) csel[i] = csel[rng.gen_range(0, i)];
+    else csel[i] = (uint32_t)rng.weighted_index(w.data(), m, cum.data()) + 1u;
   }
   (void)hipHostFree(pinned);
   VI_TRY(rc);
-  for (uint64_t i = actual_k; i < k; ++i) crow[i] = crow[rng.gen_range(0, actual_k)];
+  for (uint64_t i = actual_k; i < k; ++i) csel[i] = csel[rng.gen_range(0, actual_k)];
   DevBuf<uint32_t> d_rows;
-  VI_TRY(to_device(d_rows, crow.data(), crow.size(), cx.st));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)k), dim3(64), 0, cx.st, Xd, d_rows.p, (uint32_t)k, d, Cd);
+  VI_TRY(to_device(d_rows, csel.data(), csel.size(), cx.st));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)k), dim3(64), 0, cx.st, cand.p, d_rows.p, (uint32_t)k, d, Cd);
   VI_HIP(hipGetLastError());
   VI_HIP(hipStreamSynchronize(cx.st));
   return VI_OK;
 }
 
 // handle_empty_clusters (kmeans.rs:313-331)
-vi_status handle_empty_device(Ctx &cx, const float *Xd, uint64_t n, uint32_t d, const std::vector<uint64_t> &counts,
-                              StdRng &rng, float *Cd) {
-  std::vector<uint32_t> dst, src;
+vi_status handle_empty_rows(Ctx &cx, RowSource &src, uint64_t n, uint32_t d, const std::vector<uint64_t> &counts,
+                            StdRng &rng, float *Cd, DevBuf<float> &rowbuf) {
+  std::vector<uint32_t> dst, rows, pos;
   for (uint64_t c = 0; c < counts.size(); ++c)
-    if (counts[c] == 0) { dst.push_back((uint32_t)c); src.push_back((uint32_t)rng.gen_range(0, n)); }
+    if (counts[c] == 0) { dst.push_back((uint32_t)c); rows.push_back((uint32_t)rng.gen_range(0, n)); }
   if (dst.empty()) return VI_OK;
+  VI_TRY(rowbuf.reserve(rows.size() * (size_t)d));
+  VI_TRY(src.fetch(rows.data(), rows.size(), rowbuf.p, cx.st));
+  pos.resize(rows.size());
+  for (size_t i = 0; i < pos.size(); ++i) pos[i] = (uint32_t)i;
   DevBuf<uint32_t> d_dst, d_src;
   VI_TRY(to_device(d_dst, dst.data(), dst.size(), cx.st));
-  VI_TRY(to_device(d_src, src.data(), src.size(), cx.st));
-  hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)dst.size()), dim3(64), 0, cx.st, Xd, d_dst.p, d_src.p,
+  VI_TRY(to_device(d_src, pos.data(), pos.size(), cx.st));
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)dst.size()), dim3(64), 0, cx.st, rowbuf.p, d_dst.p, d_src.p,
                      (uint32_t)dst.size(), d, Cd);
   VI_HIP(hipGetLastError());
   VI_HIP(hipStreamSynchronize(cx.st));
@@ -483,69 +549,94 @@ vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t
   return rc;
 }
 
-vi_status kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
-                          uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run) {
-  if (thr < 0) thr = 1e-4f;  // unwrap_or(1e-4), kmeans.rs:22
-  if (n == 0 || d == 0 || !X) return fail(VI_ERR_INVALID_INPUT, "Input vectors cannot be empty");  // :23-28
-  if (k == 0) return fail(VI_ERR_INVALID_INPUT, "k must be greater than 0");
-  Ctx cx;
-  VI_TRY(cx.init(opt.device));
+// ------------------------------------------------------------------------------------------
+// per-rank pieces of the data-parallel Lloyd update (update_centroids_parallel, kmeans.rs:674-719)
+// ------------------------------------------------------------------------------------------
+// sums[c, j] = sum of X[i, j] over this rank's members of cluster c in ascending i (the reference's order inside
+// the rank), counts[c] = members.  One thread per (cluster, dim) over the stable grouping of the rank's points.
+__global__ void segment_sum_kernel(const float *X, const uint32_t *order, const uint32_t *seg_off, uint32_t k,
+                                   uint32_t d, float *sums, uint32_t *counts) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)k * d) return;
+  const uint32_t c = (uint32_t)(t / d), j = (uint32_t)(t % d);
+  const uint32_t b = seg_off[c], e = seg_off[c + 1];
+  float sum = 0.0f;
+  for (uint32_t i = b; i < e; ++i) sum += X[(size_t)order[i] * d + j];
+  sums[t] = sum;
+  if (j == 0) counts[c] = e - b;
+}
+
+// C_new[c] = sums[c] / counts[c] (zeros for an empty cluster, kmeans.rs:705-712), and the per-cluster partial of
+// compute_centroid_delta against C_prev
+__global__ void finish_update_kernel(const float *sums, const uint32_t *counts, const float *prev, uint32_t k, uint32_t d,
+                                     float *Cn, float *local) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  const uint32_t cnt = counts[c];
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < d; ++j) {
+    const float v = cnt ? sums[(size_t)c * d + j] / (float)cnt : 0.0f;
+    Cn[(size_t)c * d + j] = v;
+    const float diff = v - prev[(size_t)c * d + j];
+    acc += diff * diff;
+  }
+  local[c] = acc;
+}
+
+namespace {
+
+// run_kmeans_parallel (kmeans.rs:15-60) on device-resident points
+vi_status lloyd_core(Ctx &cx, const float *Xd, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
+                     uint64_t seed, vi_assign_mode mode, float *Cd, uint32_t *lab, uint64_t *iters_run) {
   StdRng rng(seed);
-  DevBuf<float> Xd, Cd, Cn, local;
-  DevBuf<uint32_t> lab, d_order, d_seg;
-  VI_TRY(to_device(Xd, X, n * d, cx.st));
-  VI_TRY(Cd.reserve(k * d));
+  DeviceRows src(Xd, d);
+  DevBuf<float> Cn, local, rowbuf;
+  DevBuf<uint32_t> d_order, d_seg;
   VI_TRY(Cn.reserve(k * d));
-  VI_TRY(lab.reserve(n));
-  VI_HIP(hipMemsetAsync(lab.p, 0, n * 4, cx.st));
-  VI_TRY(kmeans_pp_init_device(cx, Xd.p, n, d, k, seed, Cd.p));
+  VI_HIP(hipMemsetAsync(lab, 0, n * 4, cx.st));
+  VI_TRY(kmeans_pp_init_rows(cx, src, n, d, k, seed, Cd));
   BruteWs bws;
   std::vector<uint32_t> l32(n), order, seg;
   std::vector<uint64_t> counts(k);
   std::vector<float> h_local;
   uint64_t it = 0;
   for (; it < max_iters; ++it) {
-    VI_TRY(assign_device(cx, Xd.p, n, Cd.p, k, d, seed, opt.mode, lab.p, bws));
-    VI_HIP(hipMemcpyAsync(l32.data(), lab.p, n * 4, hipMemcpyDeviceToHost, cx.st));
+    VI_TRY(assign_device(cx, Xd, n, Cd, k, d, seed, mode, lab, bws));
+    VI_HIP(hipMemcpyAsync(l32.data(), lab, n * 4, hipMemcpyDeviceToHost, cx.st));
     VI_HIP(hipStreamSynchronize(cx.st));
     group_by_label(l32.data(), n, k, order, seg);
     VI_TRY(to_device(d_order, order.data(), order.size(), cx.st));
     VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
     const uint64_t nt = k * d;
-    hipLaunchKernelGGL(segment_mean_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd.p, d_order.p,
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd, d_order.p,
                        d_seg.p, (uint32_t)k, d, Cn.p, 0);
     VI_HIP(hipGetLastError());
     VI_HIP(hipStreamSynchronize(cx.st));
     for (uint64_t c = 0; c < k; ++c) counts[c] = seg[c + 1] - seg[c];
-    VI_TRY(handle_empty_device(cx, Xd.p, n, d, counts, rng, Cn.p));
+    VI_TRY(handle_empty_rows(cx, src, n, d, counts, rng, Cn.p, rowbuf));
     float delta = 0.0f;
-    VI_TRY(centroid_delta_device(cx, Cn.p, Cd.p, k, d, local, h_local, &delta));
-    VI_HIP(hipMemcpyAsync(Cd.p, Cn.p, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
+    VI_TRY(centroid_delta_device(cx, Cn.p, Cd, k, d, local, h_local, &delta));
+    VI_HIP(hipMemcpyAsync(Cd, Cn.p, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
     if (delta < thr) { ++it; break; }
   }
   if (iters_run) *iters_run = it;
-  VI_HIP(hipMemcpyAsync(C, Cd.p, k * d * 4, hipMemcpyDeviceToHost, cx.st));
-  return labels_to_host(cx, lab.p, n, labels);
+  VI_HIP(hipStreamSynchronize(cx.st));
+  return VI_OK;
 }
 
-vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
-                            uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run) {
-  if (thr < 0) thr = 1e-4f;  // kmeans.rs:71
-  if (n == 0 || d == 0 || !X) return fail(VI_ERR_INVALID_INPUT, "Input vectors cannot be empty");  // :72-77
-  if (k == 0) return fail(VI_ERR_INVALID_INPUT, "k must be greater than 0");
-  Ctx cx;
-  VI_TRY(cx.init(opt.device));
+// the training loop of run_kmeans_mini_batch (kmeans.rs:64-142) without its final assignment: everything it reads
+// of the data comes through `src`
+vi_status mini_batch_train_core(Ctx &cx, RowSource &src, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters,
+                                float thr, uint64_t seed, float *Cd, uint64_t *iters_run) {
   StdRng rng(seed);
   const uint64_t B = std::min<uint64_t>(vi_minibatch_size(n), n);  // kmeans.rs:83; take(batch) of n indices
-  DevBuf<float> Xd, Cd, prev, Qb, local, d_eta;
-  DevBuf<uint32_t> lab, d_bidx, d_blab, d_members, d_tc, d_ts, d_tl;
-  VI_TRY(to_device(Xd, X, n * d, cx.st));
-  VI_TRY(Cd.reserve(k * d));
+  DevBuf<float> prev, Qb, local, d_eta, rowbuf;
+  DevBuf<uint32_t> d_blab, d_members, d_tc, d_ts, d_tl;
   VI_TRY(prev.reserve(k * d));
   VI_TRY(Qb.reserve(B * d));
   VI_TRY(d_blab.reserve(B));
-  VI_TRY(kmeans_pp_init_device(cx, Xd.p, n, d, k, seed, Cd.p));
-  VI_HIP(hipMemcpyAsync(prev.p, Cd.p, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
+  VI_TRY(kmeans_pp_init_rows(cx, src, n, d, k, seed, Cd));
+  VI_HIP(hipMemcpyAsync(prev.p, Cd, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
   std::vector<uint64_t> counts(k, 0);
   std::vector<uint32_t> perm(n), bidx(B), blab(B), members, tc, ts, tl;
   std::vector<float> teta, h_local;
@@ -557,14 +648,12 @@ vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, 
     for (uint64_t i = 0; i < n; ++i) perm[i] = (uint32_t)i;
     rng.shuffle(perm.data(), n);
     std::copy(perm.begin(), perm.begin() + B, bidx.begin());
-    VI_TRY(to_device(d_bidx, bidx.data(), B, cx.st));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)B), dim3(64), 0, cx.st, Xd.p, d_bidx.p, (uint32_t)B, d, Qb.p);
-    VI_HIP(hipGetLastError());
+    VI_TRY(src.fetch(bidx.data(), B, Qb.p, cx.st));
     // batch assignment is always brute force over all k (kmeans.rs:103-110)
-    VI_TRY(assign_exact_device(cx, Qb.p, B, Cd.p, k, d, d_blab.p, bws));
+    VI_TRY(assign_exact_device(cx, Qb.p, B, Cd, k, d, d_blab.p, bws));
     VI_HIP(hipMemcpyAsync(blab.data(), d_blab.p, B * 4, hipMemcpyDeviceToHost, cx.st));
     VI_HIP(hipStreamSynchronize(cx.st));
-    // group the batch by cluster, batch order inside a cluster (kmeans.rs:739-742)
+    // group the batch by cluster, batch order inside a cluster (kmeans.rs:739-742); members = positions in the batch
     members.clear(); tc.clear(); ts.clear(); tl.clear(); teta.clear();
     std::fill(head.begin(), head.end(), kNoPos);
     std::vector<uint32_t> tail_of(k, kNoPos), touched;
@@ -580,7 +669,7 @@ vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, 
       tc.push_back(c);
       ts.push_back((uint32_t)members.size());
       uint32_t len = 0;
-      for (uint32_t b = head[c]; b != kNoPos; b = nxt[b]) { members.push_back(bidx[b]); ++len; }
+      for (uint32_t b = head[c]; b != kNoPos; b = nxt[b]) { members.push_back(b); ++len; }
       tl.push_back(len);
       counts[c] += 1;                               // per ITERATION, not per point (:757)
       teta.push_back(1.0f / (float)counts[c]);      // eta = 1/new_count (:758)
@@ -591,22 +680,183 @@ vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, 
     VI_TRY(to_device(d_tl, tl.data(), tl.size(), cx.st));
     VI_TRY(to_device(d_eta, teta.data(), teta.size(), cx.st));
     const uint64_t nt = (uint64_t)tc.size() * d;
-    hipLaunchKernelGGL(minibatch_update_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd.p,
-                       d_members.p, d_tc.p, d_ts.p, d_tl.p, d_eta.p, (uint32_t)tc.size(), d, Cd.p);
+    hipLaunchKernelGGL(minibatch_update_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Qb.p,
+                       d_members.p, d_tc.p, d_ts.p, d_tl.p, d_eta.p, (uint32_t)tc.size(), d, Cd);
     VI_HIP(hipGetLastError());
     VI_HIP(hipStreamSynchronize(cx.st));
-    VI_TRY(handle_empty_device(cx, Xd.p, n, d, counts, rng, Cd.p));
+    VI_TRY(handle_empty_rows(cx, src, n, d, counts, rng, Cd, rowbuf));
     float delta = 0.0f;
-    VI_TRY(centroid_delta_device(cx, Cd.p, prev.p, k, d, local, h_local, &delta));
-    VI_HIP(hipMemcpyAsync(prev.p, Cd.p, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
+    VI_TRY(centroid_delta_device(cx, Cd, prev.p, k, d, local, h_local, &delta));
+    VI_HIP(hipMemcpyAsync(prev.p, Cd, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
     if (delta < thr) { ++it; break; }
   }
   if (iters_run) *iters_run = it;
+  VI_HIP(hipStreamSynchronize(cx.st));
+  return VI_OK;
+}
+
+vi_status check_kmeans_args(uint64_t n, uint32_t d, uint64_t k, const void *X) {
+  if (n == 0 || d == 0 || !X) return fail(VI_ERR_INVALID_INPUT, "Input vectors cannot be empty");  // kmeans.rs:23-28,72-77
+  if (k == 0) return fail(VI_ERR_INVALID_INPUT, "k must be greater than 0");
+  if (n > 0xFFFFFFFEull) return fail(VI_ERR_INVALID_INPUT, "more than 2^32 - 2 points");
+  return VI_OK;
+}
+
+}  // namespace
+
+// run_kmeans_parallel — host-pointer form
+vi_status kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
+                          uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run) {
+  if (thr < 0) thr = 1e-4f;  // unwrap_or(1e-4), kmeans.rs:22
+  VI_TRY(check_kmeans_args(n, d, k, X));
+  Ctx cx;
+  VI_TRY(cx.init(opt.device));
+  DevBuf<float> Xd, Cd;
+  DevBuf<uint32_t> lab;
+  VI_TRY(to_device(Xd, X, n * d, cx.st));
+  VI_TRY(Cd.reserve(k * d));
+  VI_TRY(lab.reserve(n));
+  VI_TRY(lloyd_core(cx, Xd.p, n, d, k, max_iters, thr, seed, opt.mode, Cd.p, lab.p, iters_run));
+  VI_HIP(hipMemcpyAsync(C, Cd.p, k * d * 4, hipMemcpyDeviceToHost, cx.st));
+  return labels_to_host(cx, lab.p, n, labels);
+}
+
+vi_status kmeans_parallel_device(int device, const float *Xd, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters,
+                                 float thr, uint64_t seed, vi_assign_mode mode, float *Cd, uint32_t *labels_dev,
+                                 uint64_t *iters_run) {
+  if (thr < 0) thr = 1e-4f;
+  VI_TRY(check_kmeans_args(n, d, k, Xd));
+  if (!Cd || !labels_dev) return fail(VI_ERR_INVALID_INPUT, "null output pointer");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  return lloyd_core(cx, Xd, n, d, k, max_iters, thr, seed, mode, Cd, labels_dev, iters_run);
+}
+
+// run_kmeans_mini_batch — host-pointer form
+vi_status kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
+                            uint64_t seed, const KMeansOptions &opt, float *C, uint64_t *labels, uint64_t *iters_run) {
+  if (thr < 0) thr = 1e-4f;  // kmeans.rs:71
+  VI_TRY(check_kmeans_args(n, d, k, X));
+  Ctx cx;
+  VI_TRY(cx.init(opt.device));
+  DevBuf<float> Xd, Cd;
+  DevBuf<uint32_t> lab;
+  VI_TRY(to_device(Xd, X, n * d, cx.st));
+  VI_TRY(Cd.reserve(k * d));
+  DeviceRows src(Xd.p, d);
+  VI_TRY(mini_batch_train_core(cx, src, n, d, k, max_iters, thr, seed, Cd.p, iters_run));
   // final assignment of all points (kmeans.rs:144-147)
   VI_TRY(lab.reserve(n));
+  BruteWs bws;
   VI_TRY(assign_device(cx, Xd.p, n, Cd.p, k, d, seed, opt.mode, lab.p, bws));
   VI_HIP(hipMemcpyAsync(C, Cd.p, k * d * 4, hipMemcpyDeviceToHost, cx.st));
   return labels_to_host(cx, lab.p, n, labels);
+}
+
+vi_status kmeans_mini_batch_device(int device, const float *Xd, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters,
+                                   float thr, uint64_t seed, vi_assign_mode mode, float *Cd, uint32_t *labels_dev,
+                                   uint64_t *iters_run) {
+  if (thr < 0) thr = 1e-4f;
+  VI_TRY(check_kmeans_args(n, d, k, Xd));
+  if (!Cd) return fail(VI_ERR_INVALID_INPUT, "null output pointer");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  DeviceRows src(Xd, d);
+  VI_TRY(mini_batch_train_core(cx, src, n, d, k, max_iters, thr, seed, Cd, iters_run));
+  if (labels_dev) {
+    BruteWs bws;
+    VI_TRY(assign_device(cx, Xd, n, Cd, k, d, seed, mode, labels_dev, bws));
+    VI_HIP(hipStreamSynchronize(cx.st));
+  }
+  return VI_OK;
+}
+
+// the training loop alone over a caller-provided row source (data sharded over the GPUs of a node)
+vi_status kmeans_mini_batch_train(int device, const vi_row_source &rows, uint64_t n, uint32_t d, uint64_t k,
+                                  uint64_t max_iters, float thr, uint64_t seed, float *Cd, uint64_t *iters_run) {
+  if (thr < 0) thr = 1e-4f;
+  if (!rows.fetch_rows) return fail(VI_ERR_INVALID_INPUT, "vi_row_source.fetch_rows is null");
+  VI_TRY(check_kmeans_args(n, d, k, &rows));
+  if (!Cd) return fail(VI_ERR_INVALID_INPUT, "null output pointer");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  CallbackRows src(rows);
+  return mini_batch_train_core(cx, src, n, d, k, max_iters, thr, seed, Cd, iters_run);
+}
+
+vi_status kmeans_pp_init_rows_entry(int device, const vi_row_source &rows, uint64_t n, uint32_t d, uint64_t k,
+                                    uint64_t seed, float *Cd) {
+  if (!rows.fetch_rows) return fail(VI_ERR_INVALID_INPUT, "vi_row_source.fetch_rows is null");
+  VI_TRY(check_kmeans_args(n, d, k, &rows));
+  if (!Cd) return fail(VI_ERR_INVALID_INPUT, "null output pointer");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  CallbackRows src(rows);
+  return kmeans_pp_init_rows(cx, src, n, d, k, seed, Cd);
+}
+
+// per-rank partial sums / counts of the Lloyd update over this rank's points (labels from vi_assign_device)
+vi_status kmeans_partial_sums_device(int device, const float *Xd, uint64_t n, uint32_t d, const uint32_t *labels_dev,
+                                     uint64_t k, float *sums_dev, uint32_t *counts_dev) {
+  if (d == 0 || k == 0 || !sums_dev || !counts_dev || (n && (!Xd || !labels_dev)))
+    return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_kmeans_partial_sums_device");
+  if (n > 0xFFFFFFFEull) return fail(VI_ERR_INVALID_INPUT, "more than 2^32 - 2 points");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  std::vector<uint32_t> l32(n), order, seg;
+  if (n) VI_HIP(hipMemcpyAsync(l32.data(), labels_dev, n * 4, hipMemcpyDeviceToHost, cx.st));
+  VI_HIP(hipStreamSynchronize(cx.st));
+  for (uint64_t i = 0; i < n; ++i)
+    if (l32[i] >= k) return fail(VI_ERR_INVALID_INPUT, "label %u of point %llu is not below k", l32[i], (unsigned long long)i);
+  group_by_label(l32.data(), n, k, order, seg);
+  DevBuf<uint32_t> d_order, d_seg;
+  VI_TRY(to_device(d_order, order.data(), order.size(), cx.st));
+  VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
+  const uint64_t nt = k * d;
+  hipLaunchKernelGGL(segment_sum_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd, d_order.p, d_seg.p,
+                     (uint32_t)k, d, sums_dev, counts_dev);
+  VI_HIP(hipGetLastError());
+  VI_HIP(hipStreamSynchronize(cx.st));
+  return VI_OK;
+}
+
+// after the all-reduce of sums / counts: the new centroids, the RMS movement against the previous ones
+// (compute_centroid_delta, kmeans.rs:334-351) and the clusters that received no point (kmeans.rs:313-331 re-seeds them)
+vi_status kmeans_finish_update_device(int device, const float *sums_dev, const uint32_t *counts_dev, uint64_t k, uint32_t d,
+                                      const float *C_prev_dev, float *C_new_dev, float *delta_out, uint32_t *empty_out,
+                                      uint64_t *n_empty) {
+  if (d == 0 || k == 0 || !sums_dev || !counts_dev || !C_prev_dev || !C_new_dev)
+    return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_kmeans_finish_update_device");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  DevBuf<float> local;
+  VI_TRY(local.reserve(k));
+  hipLaunchKernelGGL(finish_update_kernel, dim3((uint32_t)((k + 255) / 256)), dim3(256), 0, cx.st, sums_dev, counts_dev,
+                     C_prev_dev, (uint32_t)k, d, C_new_dev, local.p);
+  VI_HIP(hipGetLastError());
+  std::vector<float> h_local(k);
+  std::vector<uint32_t> h_cnt(k);
+  VI_HIP(hipMemcpyAsync(h_local.data(), local.p, k * 4, hipMemcpyDeviceToHost, cx.st));
+  VI_HIP(hipMemcpyAsync(h_cnt.data(), counts_dev, k * 4, hipMemcpyDeviceToHost, cx.st));
+  VI_HIP(hipStreamSynchronize(cx.st));
+  float dsq = 0.0f;
+  for (uint64_t c = 0; c < k; ++c) dsq += h_local[c];
+  if (delta_out) *delta_out = std::sqrt(dsq / (float)(k * d));
+  uint64_t ne = 0;
+  for (uint64_t c = 0; c < k; ++c)
+    if (h_cnt[c] == 0) { if (empty_out) empty_out[ne] = (uint32_t)c; ++ne; }
+  if (n_empty) *n_empty = ne;
+  return VI_OK;
+}
+
+// compute_centroid_delta (kmeans.rs:334-351) of two device centroid tables
+vi_status kmeans_centroid_delta(int device, const float *cur_dev, const float *prev_dev, uint64_t k, uint32_t d, float *delta) {
+  if (!cur_dev || !prev_dev || !delta || k == 0 || d == 0) return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_kmeans_centroid_delta_device");
+  Ctx cx;
+  VI_TRY(cx.init(device));
+  DevBuf<float> local;
+  std::vector<float> h_local;
+  return centroid_delta_device(cx, cur_dev, prev_dev, k, d, local, h_local, delta);
 }
 
 }  // namespace vi

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   const uint4 *cnt4 = reinterpret_cast<const uint4 *>(cnt);  // kSubBins == 8: two uint4 per list
   uint32_t seg = 0, item = 0, run = 0, tile = 0;
-  unsigned long long vec = 0, rec = 0;
+  unsigned long long vec = 0, rec = 0, mtile = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
     const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     item += chunks * ns;
     run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * len;
-    tile += chunks * ((len + 63) / 64);  // (query group, block) tiles; < 2^24 enforced by the MFMA path's host code
+    mtile += (unsigned long long)chunks * ((len + 63) / 64);  // (query group, block) tiles ranked on the matrix cores
+    tile += chunks * ns * ((segb + 1) / 2);  // record tiles: one per (query group, 2 blocks of a segment); count checked on the host
     rec += 2ull * c * ns;
   }
   // inclusive scans across the wave, then across the 16 waves
@@ -415,11 +416,13 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   for (int o = 32; o > 0; o >>= 1) {
     vec += __shfl_xor(vec, o);
     rec += __shfl_xor(rec, o);
+    mtile += __shfl_xor(mtile, o);
   }
   if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
   if (lane == 0) {
     atomicAdd((unsigned long long *)&stats[0], vec);  // scanned vectors
     atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
+    atomicAdd((unsigned long long *)&stats[3], mtile);
   }
   __syncthreads();
   uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     u1.x = u0.w + c0.w; u1.y = u1.x + c1.x; u1.z = u1.y + c1.y; u1.w = u1.z + c1.z;
     cur4[2 * l] = u0; cur4[2 * l + 1] = u1;
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += ((c + qg - 1) / qg) * ((list_len[l] + 63) / 64);
+    rt += ((c + qg - 1) / qg) * ns * ((segb + 1) / 2);
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
@@ -450,7 +453,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     segrun_start[nlists] = trun;
     stats[1] = titem;
     stats[2] = trun;
-    stats[3] = ttile;  // (query group, block) tiles
+    stats[5] = ttile;  // pair-record tiles
   }
 }
 

@@ -40,6 +40,14 @@ class SearchStats(C.Structure):
                 ("rank_mode", u64), ("group_queries", u64)]
 
 
+FETCH_ROWS_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(u64), u64, vp)
+
+
+class RowSource(C.Structure):
+    """vi_row_source: fetch_rows(ctx, global_rows, n_rows, out_dev) -> 0 on success"""
+    _fields_ = [("ctx", vp), ("fetch_rows", FETCH_ROWS_FN)]
+
+
 class AssignStats(C.Structure):
     _fields_ = [("n", u64), ("k", u64), ("ambiguous_rows", u64), ("used_mfma", u32), ("ms_total", f32),
                 ("ms_filter", f32), ("tier1_rows", u64), ("ambiguous_rows_dev", vp), ("ambiguous_cap", u64)]
@@ -57,6 +65,16 @@ SIGNATURES = {
     "vi_assign_device": (C.c_int, [i32, vp, u64, u32, vp, u64, u64, C.c_int, vp, vp]),
     "vi_kmeans_mini_batch": (C.c_int, [vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
     "vi_kmeans_parallel": (C.c_int, [vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
+    "vi_kmeans_mini_batch_device": (C.c_int, [i32, vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
+    "vi_kmeans_parallel_device": (C.c_int, [i32, vp, u64, u32, u64, u64, f32, u64, C.c_int, vp, vp, C.POINTER(u64)]),
+    "vi_kmeans_mini_batch_train": (C.c_int, [i32, vp, u64, u32, u64, u64, f32, u64, vp, C.POINTER(u64)]),
+    "vi_kmeans_pp_init": (C.c_int, [i32, vp, u64, u32, u64, u64, vp]),
+    "vi_kmeans_partial_sums_device": (C.c_int, [i32, vp, u64, u32, vp, u64, vp, vp]),
+    "vi_kmeans_finish_update_device": (C.c_int, [i32, vp, vp, u64, u32, vp, vp, C.POINTER(f32), vp, C.POINTER(u64)]),
+    "vi_kmeans_centroid_delta_device": (C.c_int, [i32, vp, vp, u64, u32, C.POINTER(f32)]),
+    "vi_rng_seed_from_u64": (vp, [u64]),
+    "vi_rng_gen_range": (u64, [vp, u64, u64]),
+    "vi_rng_free": (None, [vp]),
     "vi_shard_save_to": (C.c_int, [C.c_char_p, u64, u32, u32, vp, vp, vp, vp, vp, vp, vp]),
     "vi_shard_get_centroid_vectors_from": (C.c_int, [C.c_char_p, u64, vp, u64, C.POINTER(u32), vp, vp, vp, vp]),
     "vi_config_init": (None, [C.POINTER(Config), u32]),

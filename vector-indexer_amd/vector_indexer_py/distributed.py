@@ -90,3 +90,205 @@ def merge_partials_reference(Dg, Ig, Tg):
         m = min(k, order.size)
         D[q, :m], I[q, :m] = d[live][order[:m]], i[live][order[:m]]
     return D, I
+
+
+# =====================================================================================================================
+# k-means with the points sharded over the GPUs of a node (X split N/world per GPU, centroids replicated)
+# =====================================================================================================================
+# The reference's k-means (src/kmeans.rs) is a single-process loop; what follows is the data-parallel form of it:
+#
+#   * the training loop of run_kmeans_mini_batch (k-means++ seeding, mini-batches, empty-cluster re-seeds) reads only
+#     the rows its rand stream names; every rank replays that stream through vi_kmeans_mini_batch_train and the
+#     named rows are exchanged by `comm.fetch_rows` (owners contribute their rows' bit patterns to an integer
+#     all-reduce, which reproduces them exactly).  Rank 0's centroids are broadcast (RCCL broadcast of k x d f32),
+#     then every rank assigns its own points: the O(N k D) part shards perfectly, labels never leave their rank.
+#   * run_kmeans_parallel (Lloyd): per iteration local assign -> per-rank sums / counts -> all-reduce(sum) of
+#     k x d f32 + k u32 -> means, re-seed of empty clusters (rows drawn from the replayed rand stream, fetched from
+#     their owners), RMS movement, early stop — identical on every rank since all of it derives from all-reduced data.
+#
+# The arithmetic runs through the C ABI (`GpuKMeansEngine`); the collectives through a communicator object
+# (`TorchComm`: torch.distributed — backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in the CPU protocol test).
+# Both are passed in, so the tests drive the same loops with N in-process ranks on one GPU and with a CPU engine.
+
+
+class ShardedPoints:
+    """this rank's slice of the points: rows [row_begin, row_begin + n_local) of the n_global x d f32 matrix, resident
+    at device pointer `ptr` (`tensor` keeps a torch tensor alive / lets TorchComm index it)"""
+
+    def __init__(self, ptr, n_local, d, row_begin, n_global, tensor=None):
+        self.ptr, self.n_local, self.d = int(ptr), int(n_local), int(d)
+        self.row_begin, self.n_global, self.tensor = int(row_begin), int(n_global), tensor
+
+
+class GpuKMeansEngine:
+    """the per-rank arithmetic of the sharded k-means, through the C ABI (raw device pointers)"""
+
+    def __init__(self, device=0):
+        from . import _native
+        self.N, self.device = _native, int(device)
+
+    def _source(self, fetch):
+        N = self.N
+
+        def cb(_ctx, rows_p, n_rows, out_dev):
+            try:
+                rows = np.ctypeslib.as_array(rows_p, shape=(int(n_rows),)).copy()
+                fetch(rows, int(out_dev))
+                return 0
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = N.FETCH_ROWS_FN(cb)
+        return N.RowSource(None, fn), fn
+
+    def mini_batch_train(self, fetch, n_global, d, k, max_iters, thr, seed, C_ptr):
+        import ctypes as C
+        src, keep = self._source(fetch)
+        it = C.c_uint64(0)
+        self.N.check(self.N.lib().vi_kmeans_mini_batch_train(self.device, C.byref(src), n_global, d, k, max_iters,
+                                                             -1.0 if thr is None else float(thr), seed, C_ptr, C.byref(it)))
+        return int(it.value)
+
+    def pp_init(self, fetch, n_global, d, k, seed, C_ptr):
+        import ctypes as C
+        src, keep = self._source(fetch)
+        self.N.check(self.N.lib().vi_kmeans_pp_init(self.device, C.byref(src), n_global, d, k, seed, C_ptr))
+
+    def assign(self, X_ptr, n_local, d, C_ptr, k, seed, mode, labels_ptr):
+        self.N.check(self.N.lib().vi_assign_device(self.device, X_ptr, n_local, d, C_ptr, k, seed, mode, labels_ptr, None))
+
+    def partial_sums(self, X_ptr, n_local, d, labels_ptr, k, sums_ptr, counts_ptr):
+        self.N.check(self.N.lib().vi_kmeans_partial_sums_device(self.device, X_ptr, n_local, d, labels_ptr, k, sums_ptr,
+                                                                counts_ptr))
+
+    def finish_update(self, sums_ptr, counts_ptr, k, d, C_prev_ptr, C_new_ptr):
+        import ctypes as C
+        empties = np.zeros(k, dtype=np.uint32)
+        ne = C.c_uint64(0)
+        self.N.check(self.N.lib().vi_kmeans_finish_update_device(self.device, sums_ptr, counts_ptr, k, d, C_prev_ptr,
+                                                                 C_new_ptr, None, empties.ctypes.data, C.byref(ne)))
+        return empties[:ne.value]
+
+    def centroid_delta(self, C_new_ptr, C_prev_ptr, k, d):
+        import ctypes as C
+        delta = C.c_float(0)
+        self.N.check(self.N.lib().vi_kmeans_centroid_delta_device(self.device, C_new_ptr, C_prev_ptr, k, d, C.byref(delta)))
+        return float(delta.value)
+
+    def rng(self, seed):
+        lib = self.N.lib()
+
+        class _Rng:
+            def __init__(s):
+                s.h = lib.vi_rng_seed_from_u64(seed)
+
+            def gen_range(s, lo, hi):
+                return int(lib.vi_rng_gen_range(s.h, lo, hi))
+
+            def __del__(s):
+                if s.h:
+                    lib.vi_rng_free(s.h)
+                    s.h = None
+        return _Rng()
+
+
+class TorchComm:
+    """collectives of the sharded k-means over torch.distributed.  Buffers are torch tensors on `device` ("cpu" with the
+    gloo backend); the C library's own device buffers (fetch_rows' destination) are reached through the HIP runtime
+    torch has loaded."""
+
+    def __init__(self, device="cpu", group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._hip = None
+
+    class Buf:
+        def __init__(self, t):
+            self.t, self.ptr = t, t.data_ptr()
+
+    def alloc(self, nbytes):
+        return TorchComm.Buf(self.torch.zeros(max(int(nbytes), 8) // 4 + 1, dtype=self.torch.int32, device=self.device))
+
+    def all_reduce_sum(self, buf, count, kind):
+        t = buf.t[:count] if kind == "u32" else buf.t[:count].view(self.torch.float32)
+        self.dist.all_reduce(t, group=self.group)
+
+    def broadcast(self, buf, nbytes, root=0):
+        self.dist.broadcast(buf.t[:(nbytes + 3) // 4], src=root, group=self.group)
+
+    def copy(self, dst_ptr, src_ptr, nbytes):
+        import ctypes as C
+        if self.device.type == "cpu":
+            C.memmove(dst_ptr, src_ptr, nbytes)
+            return
+        if self._hip is None:
+            self._hip = C.CDLL("libamdhip64.so")
+            self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.torch.cuda.synchronize(self.device)
+        if self._hip.hipMemcpy(dst_ptr, src_ptr, nbytes, 3) != 0:
+            raise RuntimeError("hipMemcpy (device to device) failed")
+
+    def fetch_rows(self, pts, rows, out_ptr):
+        """out[i] = data row rows[i]: every rank enters with the same rows; the owner of a row contributes its bit
+        pattern, every other rank zeros, and the int32 sum over the ranks is the row, exactly"""
+        torch = self.torch
+        idx = torch.from_numpy(rows.astype(np.int64)).to(self.device)
+        mine = (idx >= pts.row_begin) & (idx < pts.row_begin + pts.n_local)
+        buf = torch.zeros((idx.numel(), pts.d), dtype=torch.int32, device=self.device)
+        if pts.n_local:
+            buf[mine] = pts.tensor.view(torch.int32)[idx[mine] - pts.row_begin]
+        if self.world > 1:
+            self.dist.all_reduce(buf, group=self.group)
+        self.copy(out_ptr, buf.data_ptr(), buf.numel() * 4)
+
+
+def kmeans_mini_batch_sharded(engine, comm, pts, k, max_iters, thr=None, seed=42, mode=0):
+    """run_kmeans_mini_batch (src/kmeans.rs:64-150) over sharded points -> (centroids buffer k x d, labels buffer
+    n_local u32, iterations).  Centroids are bit-identical to the single-GPU run (the training loop sees the same rows);
+    labels are each rank's slice of the single-GPU labels."""
+    d = pts.d
+    Cb = comm.alloc(k * d * 4)
+    iters = engine.mini_batch_train(lambda rows, out: comm.fetch_rows(pts, rows, out), pts.n_global, d, k, max_iters, thr,
+                                    seed, Cb.ptr)
+    comm.broadcast(Cb, k * d * 4, 0)  # every rank replayed the same stream; rank 0's copy pins the bits
+    Lb = comm.alloc(max(pts.n_local, 1) * 4)
+    if pts.n_local:
+        engine.assign(pts.ptr, pts.n_local, d, Cb.ptr, k, seed, mode, Lb.ptr)
+    return Cb, Lb, iters
+
+
+def kmeans_parallel_sharded(engine, comm, pts, k, max_iters, thr=None, seed=42, mode=0):
+    """run_kmeans_parallel (src/kmeans.rs:15-60) over sharded points: all-reduce of the per-rank sums / counts each
+    iteration -> (centroids buffer, labels buffer, iterations)"""
+    d, n = pts.d, pts.n_global
+    thr = 1e-4 if thr is None else thr
+    fetch = lambda rows, out: comm.fetch_rows(pts, rows, out)  # noqa: E731
+    Cb, Cn = comm.alloc(k * d * 4), comm.alloc(k * d * 4)
+    Sb, Nb = comm.alloc(k * d * 4), comm.alloc(k * 4)
+    Lb = comm.alloc(max(pts.n_local, 1) * 4)
+    engine.pp_init(fetch, n, d, k, seed, Cb.ptr)
+    comm.broadcast(Cb, k * d * 4, 0)
+    rng = engine.rng(seed)  # handle_empty_clusters draws from a stream of its own (kmeans.rs:31)
+    it = 0
+    while it < max_iters:
+        engine.assign(pts.ptr, pts.n_local, d, Cb.ptr, k, seed, mode, Lb.ptr)
+        engine.partial_sums(pts.ptr, pts.n_local, d, Lb.ptr, k, Sb.ptr, Nb.ptr)
+        comm.all_reduce_sum(Sb, k * d, "f32")
+        comm.all_reduce_sum(Nb, k, "u32")
+        empties = engine.finish_update(Sb.ptr, Nb.ptr, k, d, Cb.ptr, Cn.ptr)
+        if len(empties):  # kmeans.rs:313-331: a random data row for every cluster that received no point
+            rows = np.array([rng.gen_range(0, n) for _ in empties], dtype=np.uint64)
+            Rb = comm.alloc(len(rows) * d * 4)
+            comm.fetch_rows(pts, rows, Rb.ptr)
+            for i, c in enumerate(empties):
+                comm.copy(Cn.ptr + int(c) * d * 4, Rb.ptr + i * d * 4, d * 4)
+        delta = engine.centroid_delta(Cn.ptr, Cb.ptr, k, d)
+        Cb, Cn = Cn, Cb
+        it += 1
+        if delta < thr:
+            break
+    return Cb, Lb, it
