@@ -307,6 +307,15 @@ typedef struct vi_search_stats {
                                   2 bf16 x 3 MFMA, 3 bf16 MFMA on hi planes only (bf16-exact stored values) */
   uint64_t group_queries;      /* MFMA path: queries per rank work item (128, or 32 when lists are probed by few) */
 } vi_search_stats;
+/* phases of the most recent build on this handle (wall-clock ms): the points are uploaded once; k-means, the grouping of
+ * ids by list, the shard export and the resident index all work from that device copy */
+typedef struct vi_build_stats {
+  uint64_t n, nlist, lists, shards;  /* points, requested lists, non-empty lists, shard files */
+  uint64_t shard_bytes;              /* record bytes written to the shard files */
+  float ms_total, ms_upload, ms_kmeans, ms_group, ms_super, ms_export, ms_index;
+} vi_build_stats;
+vi_status vi_indexer_last_build_stats(const vi_indexer *ix, vi_build_stats *out);
+
 /* stats of the most recent search on this handle (timing collected only if enabled) */
 vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out);
 void vi_indexer_enable_timing(vi_indexer *ix, int enable);

@@ -57,6 +57,10 @@ SETTINGS = [
     ("no restage, no store (x9)", {"VI_FILTER_XMODE": 9}),
     ("gq 32", {"VI_FILTER_GQ": 32}),
     ("bf16x3 lo planes", {"VI_FILTER_HI_ONLY": 0}),
+    ("select: no exact (s1)", {"VI_SELECT_XMODE": 1}),
+    ("select: no stage 2 (s2)", {"VI_SELECT_XMODE": 2}),
+    ("select: no stage 1b (s4)", {"VI_SELECT_XMODE": 4}),
+    ("select: stage 1a only (s7)", {"VI_SELECT_XMODE": 7}),
     ("segb 16", {"VI_FILTER_SEGB": 16}),
     ("segb 64", {"VI_FILTER_SEGB": 64}),
 ]

@@ -25,6 +25,7 @@ struct Indexer {
   std::string index_dir, shards_dir;
   IndexMeta meta;                       // IvfIndex{centroids, centroids_to_shard, dimension}
   std::unique_ptr<DeviceIndex> dev;     // HBM-resident lists (null until load/build)
+  vi_build_stats build_stats{};         // phases of the last build on this handle
 };
 
 static uint64_t unix_timestamp_secs() {  // src/utils.rs:109-114
@@ -40,7 +41,15 @@ static vi_status attach_device(Indexer *ix) {
   return VI_OK;
 }
 
-// IvfIndex::fit_with_paths (src/ivf_index.rs:58-177) + save_to (:274-294)
+static double now_ms() {
+  struct timeval tv;
+  gettimeofday(&tv, nullptr);
+  return tv.tv_sec * 1e3 + tv.tv_usec * 1e-3;
+}
+
+// IvfIndex::fit_with_paths (src/ivf_index.rs:58-177) + save_to (:274-294).  The points go to the GPU once and stay:
+// k-means, the grouping of ids by list, the blocks of the resident index and the records of the shard files all come
+// from that one device copy (list_build.hip); only the shard images travel back, to be written.
 static vi_status fit_and_save(Indexer *ix, const float *X, const uint64_t *ext_ids, const uint64_t *timestamps,
                               uint64_t n) {
   const uint32_t dim = ix->cfg.dimension;
@@ -48,30 +57,56 @@ static vi_status fit_and_save(Indexer *ix, const float *X, const uint64_t *ext_i
   const uint64_t k = ix->cfg.nlist_override ? ix->cfg.nlist_override : vi_calculate_num_clusters(n);
   const uint64_t max_iters = vi_calculate_max_iterations(n);
   const uint64_t now = ix->cfg.now_secs ? ix->cfg.now_secs : unix_timestamp_secs();
-  std::vector<float> C(k * dim);
-  std::vector<uint64_t> labels(n);
-  KMeansOptions opt;
-  opt.device = ix->cfg.device;
-  opt.mode = (vi_assign_mode)ix->cfg.assign_mode;
-  if (kmeans_mini_batch(X, n, dim, k, max_iters, -1.0f, seed, opt, C.data(), labels.data(), nullptr) != VI_OK)
+  vi_build_stats &bs = ix->build_stats;
+  bs = vi_build_stats{};
+  bs.n = n; bs.nlist = k;
+  const double t0 = now_ms();
+  if (n > 0xFFFFFFFEull) return fail(VI_ERR_INVALID_INPUT, "more than 2^32 - 2 vectors");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(VI_ERR_DEVICE, "no HIP device visible: libvi_amd never falls back to the CPU");
+  if (ix->cfg.device < 0 || ix->cfg.device >= ndev) return fail(VI_ERR_DEVICE, "device %d out of range (%d visible)", ix->cfg.device, ndev);
+  VI_HIP(hipSetDevice(ix->cfg.device));
+  hipStream_t st = nullptr;
+  VI_HIP(hipStreamCreateWithFlags(&st, hipStreamDefault));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+  DevBuf<float> Xd, Cd;
+  DevBuf<uint32_t> lab, order;
+  DevBuf<uint64_t> ext_dev, ts_dev;
+  VI_TRY(Xd.reserve(n * dim));
+  VI_HIP(hipMemcpyAsync(Xd.p, X, n * dim * sizeof(float), hipMemcpyHostToDevice, st));
+  if (ext_ids) { VI_TRY(ext_dev.reserve(n)); VI_HIP(hipMemcpyAsync(ext_dev.p, ext_ids, n * 8, hipMemcpyHostToDevice, st)); }
+  if (timestamps) { VI_TRY(ts_dev.reserve(n)); VI_HIP(hipMemcpyAsync(ts_dev.p, timestamps, n * 8, hipMemcpyHostToDevice, st)); }
+  VI_HIP(hipStreamSynchronize(st));
+  const double t1 = now_ms();
+  bs.ms_upload = (float)(t1 - t0);
+  VI_TRY(Cd.reserve(k * dim));
+  VI_TRY(lab.reserve(n));
+  if (kmeans_mini_batch_device(ix->cfg.device, Xd.p, n, dim, k, max_iters, -1.0f, seed, (vi_assign_mode)ix->cfg.assign_mode,
+                               Cd.p, lab.p, nullptr) != VI_OK)
     return fail(VI_ERR_PANIC, "Failed to run KMeans: %s", last_error_ref().c_str());  // .expect (ivf_index.rs:71)
-  // IVF lists in ascending internal id (:94-101): counting sort of ids by label
-  std::vector<uint64_t> off(k + 1, 0);
-  for (uint64_t i = 0; i < n; ++i) off[labels[i] + 1]++;
-  for (uint64_t c = 0; c < k; ++c) off[c + 1] += off[c];
-  std::vector<uint64_t> order(n);
-  {
-    std::vector<uint64_t> cur(off.begin(), off.end() - 1);
-    for (uint64_t i = 0; i < n; ++i) order[cur[labels[i]]++] = i;
-  }
+  std::vector<float> C(k * dim);
+  VI_HIP(hipMemcpy(C.data(), Cd.p, k * dim * sizeof(float), hipMemcpyDeviceToHost));
+  const double t2 = now_ms();
+  bs.ms_kmeans = (float)(t2 - t1);
+  // IVF lists in ascending internal id (:94-101): ids grouped by label on the device
+  std::vector<uint64_t> off;
+  VI_TRY(group_ids_by_label_device(lab.p, n, k, order, off, st));
+  const double t3 = now_ms();
+  bs.ms_group = (float)(t3 - t2);
   // super-centroids => shard of every list (:104-109)
   const uint64_t num_shards = (uint64_t)std::ceil(std::sqrt((float)k));
   const uint64_t super_seed = seed * 31ULL + 7ULL;
   std::vector<float> SC(num_shards * dim);
   std::vector<uint64_t> slab(k);
+  KMeansOptions opt;
+  opt.device = ix->cfg.device;
+  opt.mode = (vi_assign_mode)ix->cfg.assign_mode;
   if (kmeans_mini_batch(C.data(), k, dim, num_shards, 100, -1.0f, super_seed, opt, SC.data(), slab.data(), nullptr) !=
       VI_OK)
     return fail(VI_ERR_PANIC, "Failed to run kmeans: %s", last_error_ref().c_str());
+  const double t4 = now_ms();
+  bs.ms_super = (float)(t4 - t3);
   // drop empty lists and renumber (:123-164)
   std::vector<uint64_t> newid(k, ~0ull);
   uint64_t kk = 0;
@@ -80,36 +115,59 @@ static vi_status fit_and_save(Indexer *ix, const float *X, const uint64_t *ext_i
   ix->meta.dimension = dim;
   ix->meta.centroids.assign(kk * dim, 0.0f);
   ix->meta.c2s.assign(kk, 0);
+  std::vector<uint64_t> src_off(kk);
+  std::vector<uint32_t> len(kk), lshard(kk);
+  std::vector<std::vector<uint32_t>> of_shard(num_shards);  // kept lists of every shard, ascending
   for (uint64_t c = 0; c < k; ++c)
     if (newid[c] != ~0ull) {
-      std::memcpy(&ix->meta.centroids[newid[c] * dim], &C[c * dim], dim * sizeof(float));
-      ix->meta.c2s[newid[c]] = slab[c];
+      const uint64_t l = newid[c];
+      std::memcpy(&ix->meta.centroids[l * dim], &C[c * dim], dim * sizeof(float));
+      ix->meta.c2s[l] = slab[c];
+      src_off[l] = off[c];
+      len[l] = (uint32_t)(off[c + 1] - off[c]);
+      lshard[l] = (uint32_t)slab[c];
+      of_shard[slab[c]].push_back((uint32_t)l);
     }
   // every shard is written, also the ones that received no list (:118-120,166-171)
-  for (uint64_t s = 0; s < num_shards; ++s) {
-    std::vector<uint64_t> cids, loff{0}, ids, eids, tss;
-    std::vector<float> cvec, vv;
-    for (uint64_t c = 0; c < k; ++c) {
-      if (newid[c] == ~0ull || slab[c] != s) continue;
-      cids.push_back(newid[c]);
-      cvec.insert(cvec.end(), &C[c * dim], &C[c * dim] + dim);
-      for (uint64_t e = off[c]; e < off[c + 1]; ++e) {
-        const uint64_t i = order[e];
-        ids.push_back(i);                                    // internal id = position (vector_store.rs:33)
-        eids.push_back(ext_ids ? ext_ids[i] : i);
-        const uint64_t ts = timestamps ? timestamps[i] : 0;
-        tss.push_back(ts != 0 ? ts : now);                   // vector_store.rs:36-40
-        vv.insert(vv.end(), X + i * dim, X + (i + 1) * dim);
+  {
+    ShardExportWs ws;
+    std::vector<uint64_t> cids, soff;
+    std::vector<uint32_t> slen;
+    std::vector<float> cvec;
+    for (uint64_t s = 0; s < num_shards; ++s) {
+      cids.clear(); soff.clear(); slen.clear(); cvec.clear();
+      for (uint32_t l : of_shard[s]) {
+        cids.push_back(l);
+        soff.push_back(src_off[l]);
+        slen.push_back(len[l]);
+        cvec.insert(cvec.end(), &ix->meta.centroids[(uint64_t)l * dim], &ix->meta.centroids[(uint64_t)l * dim] + dim);
+        bs.shard_bytes += (uint64_t)len[l] * record_stride(dim);
       }
-      loff.push_back(ids.size());
+      // a failed shard write is only reported, never fatal (ivf_index.rs:168-170)
+      if (shard_export_device(ix->shards_dir, s, dim, cids, cvec.data(), soff, slen, Xd.p, order.p,
+                              ext_ids ? ext_dev.p : nullptr, timestamps ? ts_dev.p : nullptr, now, ws, st) != VI_OK)
+        fprintf(stderr, "Failed to write shard %llu to disk: %s\n", (unsigned long long)s, last_error_ref().c_str());
     }
-    // a failed shard write is only reported, never fatal (ivf_index.rs:168-170)
-    if (shard_save_to(ix->shards_dir, s, dim, (uint32_t)cids.size(), cids.data(), cvec.data(), loff.data(),
-                      ids.data(), eids.data(), tss.data(), vv.data()) != VI_OK)
-      fprintf(stderr, "Failed to write shard %llu to disk: %s\n", (unsigned long long)s, last_error_ref().c_str());
   }
   VI_TRY(index_meta_save(ix->meta, ix->index_dir));
-  return attach_device(ix);
+  const double t5 = now_ms();
+  bs.ms_export = (float)(t5 - t4);
+  // the resident index: straight from the device copy (a rank of a multi-GPU run keeps only its stripes: from the files)
+  vi_status rc;
+  if (ix->cfg.world_size > 1) {
+    rc = attach_device(ix);
+  } else {
+    auto dev = std::make_unique<DeviceIndex>();
+    rc = device_index_from_order(ix->cfg.device, dim, ix->meta.centroids.data(), kk, Xd.p, order.p, src_off, len, lshard,
+                                 ext_ids ? ext_dev.p : nullptr, dev.get());
+    if (rc == VI_OK) ix->dev = std::move(dev);
+  }
+  const double t6 = now_ms();
+  bs.ms_index = (float)(t6 - t5);
+  bs.ms_total = (float)(t6 - t0);
+  bs.lists = kk;
+  bs.shards = num_shards;
+  return rc;
 }
 
 }  // namespace vi
@@ -438,6 +496,12 @@ vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out) {
   if (!ix || !out || !ix->impl.dev) return fail(VI_ERR_INVALID_INPUT, "no stats");
   std::lock_guard<std::mutex> lock(ix->impl.dev->mu);
   *out = ix->impl.dev->stats;
+  return VI_OK;
+}
+
+vi_status vi_indexer_last_build_stats(const vi_indexer *ix, vi_build_stats *out) {
+  if (!ix || !out) return fail(VI_ERR_INVALID_INPUT, "no stats");
+  *out = ix->impl.build_stats;
   return VI_OK;
 }
 

@@ -86,6 +86,7 @@ struct DeviceIndex {
   DevBuf<uint64_t> ext_ids;           // [lists.nblocks*64]
   uint32_t stripe_rank = 0, stripe_world = 1;  // multi-GPU: block b of a list lives on rank b % world
   DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (3e38 on pad slots)
+  DevBuf<float> xnorm_img, cent_xnorm_img;  // the same in the column order of the bf16 images (filter_search.hip: image_column)
   DevBuf<uint32_t> lists_bf16, cent_bf16;  // bf16 hi/lo images of the blocks for the MFMA ranking (filter_search.hip)
   bool lists_lo_zero = false, cent_lo_zero = false;  // every stored value is bf16-exact (lo planes all zero)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
@@ -133,6 +134,29 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
                                  const float *rows_dev, const std::vector<uint64_t> &list_off,
                                  const std::vector<uint32_t> &member_rows, const uint64_t *ids_dev,
                                  const std::vector<uint32_t> *list_shard, DeviceIndex *out);
+
+// ---- GPU list build (list_build.hip) ----
+// ids 0..n-1 grouped by label, ascending id inside a label: order (device, n u32) and off[k+1] (host)
+vi_status group_ids_by_label_device(const uint32_t *labels_dev, uint64_t n, uint64_t k, DevBuf<uint32_t> &order,
+                                    std::vector<uint64_t> &off, hipStream_t st);
+// resident index straight from device data: list l = rows order[src_off[l] .. + len[l]) of X_dev
+vi_status device_index_from_order(int device, uint32_t dim, const float *table_host, uint64_t nlists, const float *X_dev,
+                                  const uint32_t *order_dev, const std::vector<uint64_t> &src_off,
+                                  const std::vector<uint32_t> &len, const std::vector<uint32_t> &list_shard,
+                                  const uint64_t *ids_dev, DeviceIndex *out);
+struct ShardExportWs {  // staging of shard_export_device, reused from shard to shard
+  DevBuf<uint8_t> image;
+  DevBuf<uint64_t> d_src, d_dst;
+  DevBuf<uint32_t> d_len, d_first;
+  uint8_t *host = nullptr;  // pinned
+  uint64_t host_cap = 0;
+  ~ShardExportWs();
+};
+// shard_<id>.bin from device-resident points, byte-identical to shard_save_to (shards.cpp)
+vi_status shard_export_device(const std::string &shards_dir, uint64_t shard_id, uint32_t dim, const std::vector<uint64_t> &cids,
+                              const float *cvecs_host, const std::vector<uint64_t> &src_off, const std::vector<uint32_t> &len,
+                              const float *X_dev, const uint32_t *order_dev, const uint64_t *ext_dev, const uint64_t *ts_dev,
+                              uint64_t now, ShardExportWs &ws, hipStream_t st);
 
 vi_status merge_partials_packed_device(int device, uint64_t nq, uint64_t k, uint32_t parts, const void *packed,
                                        float *D_out, int64_t *I_out);

@@ -101,6 +101,15 @@ __global__ void pad_norms_kernel(const uint32_t *first_block, const uint32_t *li
 // f32 blocks [quad][64] float4 -> bf16 blocks [chunk of 16 dims][plane hi/lo][half of 8 dims][64] x 16 B: the
 // image a 32x32x16 MFMA wants (lane (j,h) reads the 8 consecutive dims 16c+8h.. of vector j as one ds_read_b128),
 // same bytes per block as the f32 form
+// Column of vector v (0..63 of its block) in the bf16 image.  A lane of lane half h ends an MFMA holding rows
+// (e&3) + 8(e>>2) + 4h (e = 0..15) of each 32-row tile: a SUB-BLOCK, the unit the select re-evaluates exactly.  The image
+// places vectors so that sub-block (tile t, half h) is the 16 CONSECUTIVE vectors 32t + 16h .. + 15 of the block: their
+// f32 quads are 256 contiguous bytes, two whole cache lines, where the identity placement touched half of four.
+__host__ __device__ inline uint32_t image_column(uint32_t v) {
+  const uint32_t t = v >> 5, h = (v >> 4) & 1u, e = v & 15u;
+  return 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * h;
+}
+
 __global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, uint4 *out) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block, chunk, half, vector)
   const uint32_t nc = dq / 4;
@@ -113,8 +122,15 @@ __global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nb
   uint4 hi, lo;
   split8(src[0], src[64], 1.0f, hi, lo);
   uint4 *dst = out + ((b * nc + c) * 4) * 64;
-  dst[(0 * 2 + h) * 64 + v] = hi;
-  dst[(1 * 2 + h) * 64 + v] = lo;
+  const uint32_t col = image_column(v);
+  dst[(0 * 2 + h) * 64 + col] = hi;
+  dst[(1 * 2 + h) * 64 + col] = lo;
+}
+
+// the squared norms in image order (the accumulator of MFMA row i starts at the norm of the vector in column i)
+__global__ void image_norms_kernel(const float *xnorm, uint64_t nslots, float *out) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nslots) out[(s & ~63ull) + image_column((uint32_t)(s & 63u))] = xnorm[s];
 }
 
 // any nonzero lo half in an image? (pieces of 64 uint4: plane = (piece >> 1) & 1)
@@ -494,6 +510,8 @@ struct SelectCommon {
   float gamma, e_scale, xmax2;
   uint32_t gq;  // queries per rank work item (a record tile holds 2 * gq pair records)
   unsigned long long *dbg;  // [6] exact re-evaluations, [7] groups whose pair records were read, [8..] see select_body
+  uint32_t image_order;     // the rank kernel multiplied the permuted bf16 image (subblock_vector)
+  uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
 };
 
 // the query's probes, one per lane r < P
@@ -506,20 +524,23 @@ struct ProbeRegs {
   uint32_t g;         // candidate-order rank (shard visiting order)
 };
 
-// exact distance of one (query row, stored vector) pair, one lane per pair (src/utils.rs:28-30)
+// exact distance of one (query row, stored vector) pair, one lane per pair (src/utils.rs:28-30).  The query row sits
+// in LDS (every lane reads the same address: a broadcast, no vector-memory slot), so all eight loads in flight per
+// lane are the stored vector's
 __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv, uint32_t dim) {
   const float4 *xq = reinterpret_cast<const float4 *>(qrow);
   float acc = 0.0f;
   const uint32_t nquad = dim >> 2;
   uint32_t qd = 0;
-  for (; qd + 4 <= nquad; qd += 4) {  // 8 independent 16-byte loads in flight per lane
-    const float4 q0 = xq[qd], q1 = xq[qd + 1], q2 = xq[qd + 2], q3 = xq[qd + 3];
-    const float4 x0 = xv[(size_t)qd * kWave], x1 = xv[(size_t)(qd + 1) * kWave];
-    const float4 x2 = xv[(size_t)(qd + 2) * kWave], x3 = xv[(size_t)(qd + 3) * kWave];
-    sq_add(acc, q0.x, x0.x); sq_add(acc, q0.y, x0.y); sq_add(acc, q0.z, x0.z); sq_add(acc, q0.w, x0.w);
-    sq_add(acc, q1.x, x1.x); sq_add(acc, q1.y, x1.y); sq_add(acc, q1.z, x1.z); sq_add(acc, q1.w, x1.w);
-    sq_add(acc, q2.x, x2.x); sq_add(acc, q2.y, x2.y); sq_add(acc, q2.z, x2.z); sq_add(acc, q2.w, x2.w);
-    sq_add(acc, q3.x, x3.x); sq_add(acc, q3.y, x3.y); sq_add(acc, q3.z, x3.z); sq_add(acc, q3.w, x3.w);
+  for (; qd + 8 <= nquad; qd += 8) {
+    float4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xv[(size_t)(qd + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 qq = xq[qd + i];
+      sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
+    }
   }
   for (; qd < nquad; ++qd) {
     const float4 qq = xq[qd];
@@ -546,12 +567,14 @@ __device__ __attribute__((noinline)) WaveTopK exact_batch_fn(WaveTopK sel, const
   return sel;
 }
 
-// vector (within its 64-vector block) of row e (0..15) of sub-block (tile t, lane half hh): the 32x32 accumulator of
-// tile t holds rows (e&3) + 8(e>>2) + 4hh of the tile in the 16 registers of a lane of half hh
-__device__ __forceinline__ uint32_t subblock_vector(uint32_t e, uint32_t t, uint32_t hh) {
-  return 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * hh;
+// vector (within its 64-vector block) of row e (0..15) of sub-block (tile t, lane half hh): the bf16 images are built
+// so that it is 32t + 16hh + e (image_column); the f32 MFMA (VI_FILTER_BF16=0) multiplies the f32 blocks as they
+// are, where the 16 registers of a lane of half hh hold rows (e&3) + 8(e>>2) + 4hh of the tile
+__device__ __forceinline__ uint32_t subblock_vector(uint32_t e, uint32_t t, uint32_t hh, bool image_order) {
+  return image_order ? 32u * t + 16u * hh + e : 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * hh;
 }
 
+constexpr uint32_t kMaxFilterDim = 128;  // the MFMA engine's dimension limit (filter_path_applicable)
 constexpr uint32_t kPickCap = 256;     // sub-blocks waiting for their 16 exact distances (per wave)
 constexpr uint32_t kSubBits = 21;      // request key = (probe rank << 22) | (sub-block of the list << 1) | lane half
 constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/half) kept in LDS per wave
@@ -560,7 +583,7 @@ constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/
 // Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick, float4 *tcache,
-                                            uint32_t *lcache, WaveTopK &sel) {
+                                            uint32_t *lcache, float *qlds, WaveTopK &sel) {
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -568,7 +591,11 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   float qn = 0.0f;
-  for (uint32_t e = lane; e < c.dim; e += kWave) { const float v = c.Q[(size_t)q * c.dim + e]; qn += v * v; }
+  for (uint32_t e = lane; e < c.dim; e += kWave) {  // the query row: into LDS for the exact evaluations, and its norm
+    const float v = c.Q[(size_t)q * c.dim + e];
+    qlds[e] = v;
+    qn += v * v;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
   const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
@@ -584,12 +611,12 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   WaveTopK s1;
   float thr = INFINITY;
   sel.init();
-  const float *qrow = c.Q + (size_t)q * c.dim;
+  const float *qrow = qlds;  // (visible to the wave after the lds_sync of stage 0)
   auto exact_offer = [&](bool live, uint32_t r, uint32_t pos) {  // one (probe rank, position) per lane
     const uint32_t fb = (uint32_t)__shfl((int)pr.fb, (int)r);
     const uint32_t g = (uint32_t)__shfl((int)pr.g, (int)r);
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
-    live = live && pos < len;
+    live = live && pos < len && !(c.xmode & 1u);
     n_exact += (uint32_t)__popcll(__ballot(live));
     sel = exact_batch_fn(sel, qrow, c.blocks + ((size_t)(fb + (live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave),
                          c.dim, live, (g << kPosBits) | pos, (int)K);
@@ -603,7 +630,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       const bool live = rq < cnt;
       const uint32_t ck = live ? pick[npick + rq] : 0u;
       const uint32_t r = ck >> (kSubBits + 1), sub = (ck >> 1) & ((1u << kSubBits) - 1u), hh = ck & 1u;
-      exact_offer(live, r, (sub >> 1) * kWave + subblock_vector((uint32_t)lane & 15u, sub & 1u, hh));
+      exact_offer(live, r, (sub >> 1) * kWave + subblock_vector((uint32_t)lane & 15u, sub & 1u, hh, c.image_order != 0u));
     }
   };
   auto push_sub = [&](bool want, uint32_t r, uint32_t sub, uint32_t hh) {  // every lane calls
@@ -732,7 +759,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   //      loose; the pair records of those groups list every sub-block minimum.  Their values REPLACE the
   //      group's own (which are among them, so they must not be counted twice): drop the group's entries from
   //      the running top-K, then offer its pair records ----
-  if (any_full && !distrust) {
+  if (any_full && !distrust && !(c.xmode & 4u)) {
     {
       const bool mine = s1.p != kNoPos && (uint32_t)lane < K;  // entries beyond the K-th are not needed
       const uint32_t g = mine ? (s1.p >> 2) : 0u;
@@ -777,7 +804,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     group_place(gidx, live, r, seg, hh);
     const float4 T = group_values(gidx, live);
     n_full += (uint32_t)__popcll(__ballot(live && T.w <= thr));
-    scan_groups(live && !(T.x > thr), r, seg, hh, 1);
+    scan_groups(live && !(T.x > thr) && !(c.xmode & 2u), r, seg, hh, 1);
   }
   drain_pick();
   if (c.dbg && lane == 0) {
@@ -805,6 +832,7 @@ struct SelectArgs {
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
+  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -826,7 +854,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   }
   WaveTopK sel;
   select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
-              s_lcache[wave], sel);
+              s_lcache[wave], s_q[wave], sel);
   // lane i holds result i: map the candidate-order rank g back to the probe rank r
   const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
   uint32_t r = 0;
@@ -870,6 +898,7 @@ struct CoarseSelectArgs {
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
+  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -880,7 +909,7 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   }
   WaveTopK sel;
   select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
-              s_lcache[wave], sel);
+              s_lcache[wave], s_q[wave], sel);
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
@@ -974,9 +1003,11 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.e_scale = (float)acc;
   c.xmax2 = xmax2;
   c.gq = gq;
+  c.image_order = rank_bf16() ? 1u : 0u;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.ws.stats.p : nullptr;
+  { const char *xm = getenv("VI_SELECT_XMODE"); c.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
   return c;
 }
 
@@ -1026,6 +1057,15 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
   VI_HIP(hipStreamSynchronize(ix->stream));
   std::memcpy(&f, &bits, 4);
   ix->cent_xmax2 = f;
+  VI_TRY(ix->xnorm_img.reserve(std::max<uint64_t>(1, nslots)));
+  VI_TRY(ix->cent_xnorm_img.reserve(std::max<uint64_t>(1, cslots)));
+  if (nslots)
+    hipLaunchKernelGGL(image_norms_kernel, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, ix->stream, ix->xnorm.p,
+                       nslots, ix->xnorm_img.p);
+  if (cslots)
+    hipLaunchKernelGGL(image_norms_kernel, dim3((uint32_t)((cslots + 255) / 256)), dim3(256), 0, ix->stream,
+                       ix->cent_xnorm.p, cslots, ix->cent_xnorm_img.p);
+  VI_HIP(hipGetLastError());
   // bf16 hi/lo images of the lists and of the centroid table (same size as the f32 blocks)
   if ((ix->dim & 3) == 0 && ix->dim <= 128) {
     const uint64_t per_block = (uint64_t)ix->dq * kWave * 4;  // uint32 words per block
@@ -1101,7 +1141,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   {
     FilterArgs a{};
     a.blocks = rank_bf16() ? (const float4 *)ix.cent_bf16.p : (const float4 *)ix.centroids.blocks.p;
-    a.xnorm = ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
+    a.xnorm = rank_bf16() ? ix.cent_xnorm_img.p : ix.cent_xnorm.p; a.dq = dq; a.dim = dim; a.Q = Qd;
     a.first_block = ix.c_first.p; a.list_len = ix.c_len.p; a.item_start = ws.c_item.p; a.seg_start = ws.c_seg.p;
     a.pairs = ws.c_pairs.p; a.nlists = 1; a.P = 1; a.segb0 = segb0;
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
@@ -1114,6 +1154,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
                        (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
                        ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
+    { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
     hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
@@ -1198,7 +1239,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   {
     FilterArgs a{};
     a.blocks = rank_bf16() ? (const float4 *)ix.lists_bf16.p : (const float4 *)ix.lists.blocks.p;
-    a.xnorm = ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
+    a.xnorm = rank_bf16() ? ix.xnorm_img.p : ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
     a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
     a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
     a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;

@@ -190,6 +190,9 @@ __global__ void generic_output_kernel(OutArgs a) {
 
 }  // namespace
 
+// device-wide sort of rows of 2^logL u64 keys (list_build.hip groups the point ids by list with it)
+vi_status sort_rows_u64(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream_t st) { return sort_rows(keys, nrows, logL, st); }
+
 // declared in search_kernels.hip
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[6], hipStream_t st, bool histogram_done);

@@ -924,6 +924,10 @@ static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, ui
   return VI_OK;
 }
 
+vi_status init_device_index_pub(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists) {
+  return init_device_index(ix, device, dim, nlists);
+}
+
 vi_status device_index_from_rows(int device, int order, uint32_t dim, const float *table_dev, uint64_t ntable,
                                  const float *rows_dev, const std::vector<uint64_t> &list_off,
                                  const std::vector<uint32_t> &member_rows, const uint64_t *ids_dev,

@@ -110,6 +110,11 @@ class VectorIndex:
         _native.check(lib().vi_indexer_last_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def build_stats(self) -> dict:
+        st = _native.BuildStats()
+        _native.check(lib().vi_indexer_last_build_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
     # device-pointer search used by the multi-GPU path (torch tensors on this GPU)
     def search_device(self, xq_ptr: int, nq: int, k: int, n_probe: int, D_ptr: int, I_ptr: int, tie_ptr: int = 0):
         _native.check(lib().vi_indexer_search_device(self._h, C.c_void_p(xq_ptr), nq, k, n_probe, C.c_void_p(D_ptr),

@@ -40,6 +40,12 @@ class SearchStats(C.Structure):
                 ("rank_mode", u64), ("group_queries", u64)]
 
 
+class BuildStats(C.Structure):
+    _fields_ = [("n", u64), ("nlist", u64), ("lists", u64), ("shards", u64), ("shard_bytes", u64), ("ms_total", f32),
+                ("ms_upload", f32), ("ms_kmeans", f32), ("ms_group", f32), ("ms_super", f32), ("ms_export", f32),
+                ("ms_index", f32)]
+
+
 FETCH_ROWS_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(u64), u64, vp)
 
 
@@ -97,6 +103,7 @@ SIGNATURES = {
     "vi_indexer_free": (None, [vp]),
     "vi_indexer_last_stats": (C.c_int, [vp, C.POINTER(SearchStats)]),
     "vi_indexer_enable_timing": (None, [vp, C.c_int]),
+    "vi_indexer_last_build_stats": (C.c_int, [vp, C.POINTER(BuildStats)]),
 }
 
 _lib = None
