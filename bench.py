@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the IVF search hot path on MI355X.
 
-Metric (BASELINE.json): QPS at recall@10 >= 0.95 on SIFT1M (N=1e6, D=128, IVF k=4096, nprobe sweep,
-headline nprobe=32), search on 1 x MI355X.  SIFT1M is not available offline, so the workload is the
-documented SIFT-shaped synthetic set of the same size (see make_dataset); `data` says so.
+Metric (BASELINE.json): QPS at recall@10 >= 0.95 on SIFT1M — config C2: N=1e6, D=128, IVF k=4096, nprobe=32, search on
+1 x MI355X.  SIFT1M is not available offline, so the default workload is the SIFT-shaped synthetic set of the same size
+(make_dataset); `data` says so.  With --base/--query[/--gt] (.fvecs/.ivecs/.npy) the real files are used instead.
 
-A "step" = one pass of the search hot path (coarse quantizer -> list scan -> top-k) over one batch
-of NQ queries that are already resident in HBM.  value = queries/s over the timed steps.
+A "step" = one pass of the search hot path (coarse quantizer -> list ranking -> exact top-k) over one batch of NQ
+queries that are already resident in HBM.  value = queries/s over the timed steps at BASELINE's nprobe (32).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same index is partitioned by
-block over the ranks (block b of every list on rank b % N), every rank searches the full query batch against the
-lists it owns, the per-rank top-k are exchanged with ONE all-gather over RCCL (after one all-gather of the probe
-lists: the coarse step is split over the ranks by query) and merged with the
-reference's stable candidate order.  Total work is fixed => "scaling": "strong".
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same index is partitioned over the ranks (stripes:
+block b of every list on rank b % N; or --placement shards: whole shard files, greedy by bytes), the coarse step is
+split over the ranks by query (one all-gather of the probe lists), every rank ranks the whole batch against what it
+owns, the per-rank top-k are exchanged with ONE all-gather over RCCL and merged with the reference's stable candidate
+order.  Total work is fixed => "scaling": "strong".
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  Besides the contract's fields it carries: roofline (dominant kernel, measured live with
+HIP events on the library's stream), cpu_baseline (the oracle on the host cores, bounded sample), and `extras`: the
+smallest nprobe reaching recall 0.95, the host-pointer entry, small-batch latencies, real-valued data (bf16 x 3 ranking),
+config C1 on the CPU path and on the GPU, the k-means lines (C3 exact assign, update pass, reference-compat train).
 """
 import argparse
 import json
@@ -25,6 +28,7 @@ import shutil
 import sys
 import tempfile
 import time
+
 
 # libgomp reads these once, when torch first loads it: cap the CPU baseline's OpenMP team to the CPUs
 # this job may really use (the GPU box shows 256 cores to nproc but grants a 16-CPU share)
@@ -48,9 +52,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vector-indexer_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TF = 157.3  # dense f32 matrix peak: 256 CUs x 256 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3    # dense f32 matrix peak: 256 CUs x 256 flop/clk x 2.4 GHz
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 matrix peak: 256 CUs x 4096 flop/clk x 2.4 GHz
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_scan_traffic.json")
 
 
 def make_dataset(n, d, nq, seed, device):
@@ -62,6 +67,7 @@ def make_dataset(n, d, nq, seed, device):
     g.manual_seed(seed)
     ncomp = 2048
     centers = torch.randn(ncomp, d, generator=g, device=device) * 30.0 + 60.0
+
     def draw(m):
         comp = torch.randint(0, ncomp, (m,), generator=g, device=device)
         x = centers[comp] + torch.randn(m, d, generator=g, device=device) * 14.0
@@ -79,7 +85,7 @@ def ground_truth(xb, xq, k):
     for s in range(0, nb, 131072):
         blk = xb[s:s + 131072]
         dist = qn - 2.0 * (xq @ blk.T) + (blk * blk).sum(1)[None, :]
-        dd, ii = torch.topk(dist, k, dim=1, largest=False)
+        dd, ii = torch.topk(dist, min(k, blk.shape[0]), dim=1, largest=False)
         cat_d = torch.cat([best_d, dd], 1)
         cat_i = torch.cat([best_i, ii + s], 1)
         sel = torch.topk(cat_d, k, dim=1, largest=False)
@@ -90,11 +96,58 @@ def ground_truth(xb, xq, k):
 def recalls(I, gt):
     """(1-NN-in-top-k recall of the reference's harness, bench_all_ivf.py:336-350;
         intersection recall of the Rust tests, tests/test_utils/mod.rs:214-221)"""
-    import torch
     k = I.shape[1]
     r1 = (I == gt[:, :1]).any(dim=1).float().mean().item()
     inter = (I[:, :, None] == gt[:, None, :k]).any(dim=2).float().sum(dim=1).mean().item() / k
     return r1, inter
+
+
+def time_steps(fn, steps, warmup, barrier, world, device):
+    """W untimed + exactly K timed steps, bracketed by barrier + synchronize; MAX over the ranks"""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def roofline_of(st, scan_ms, d, world_note=""):
+    """roofline of the dominant kernel (list ranking) from the library's own HIP-event time of that kernel.
+    bound = "mfma": a batch turns the list scan into a dense contraction (2*D flop per (query, scanned vector) pair)
+    whose floor on this chip is the matrix pipe (0.06 ms at C2), above the HBM floor of streaming the index once
+    (0.04 ms).  Both fractions are printed; `traffic` = HBM-side bytes per launch from the committed PMC passes."""
+    scan_s = scan_ms / 1000.0
+    pairs = float(st["scanned_vectors"])
+    if st["filter_tile_blocks"] > 0:
+        mode = int(st["rank_mode"])  # 1 f32 MFMA, 2 bf16x3, 3 bf16 on hi planes only
+        flops = 2.0 * d * pairs
+        tf = flops / scan_s / 1e12 if scan_s > 0 else 0.0
+        peak = MFMA_F32_PEAK_TF if mode == 1 else MFMA_BF16_PEAK_TF
+        name = {1: "filter_kernel<NG,1,false,0,GQ> (f32 MFMA ranking)",
+                2: "filter_kernel<NG,1,false,1,GQ> (bf16 MFMA ranking, operands split hi+lo: 3 MFMAs per 16 dims)",
+                3: "filter_kernel<NG,2,false,2,GQ> (bf16 MFMA ranking, hi planes only: stored values are bf16-exact)"}[mode]
+        return {"kernel": name + " of (query group x list segment) tiles", "bound": "mfma", "achieved": round(tf, 1),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                "flops_per_launch": flops, "avg_launch_ms": round(scan_ms, 4), "tiles_per_launch": int(st["filter_tile_blocks"]),
+                "queries_per_work_item": int(st["group_queries"]) or 128,
+                "peak_note": ("dense f32 MFMA peak" if mode == 1 else "dense bf16 MFMA peak (no sparsity)") +
+                             "; useful flops = 2*D per (query, scanned vector) pair" +
+                             (", the 3 split products of bf16x3 are overhead, not counted" if mode == 2 else "") + world_note}
+    algo = pairs * (4 * d + 8)  # SURVEY 8d: 4*D per vector + 8 B id, no reuse
+    gbs = algo / scan_s / 1e9 if scan_s > 0 else 0.0
+    return {"kernel": "scan_kernel<LISTS> (exact-order VALU list scan + wave top-k)", "bound": "hbm", "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(scan_ms, 4), "algorithmic_bytes_per_launch": int(algo)}
 
 
 def main():
@@ -107,10 +160,15 @@ def main():
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--nprobe", type=int, default=0, help="0 = smallest of the sweep with recall@10 >= 0.95")
+    ap.add_argument("--nprobe", type=int, default=32, help="headline operating point (BASELINE configs[1]: 32)")
+    ap.add_argument("--base", default=None, help="database vectors (.fvecs / .npy), e.g. sift_base.fvecs")
+    ap.add_argument("--query", default=None, help="query vectors (.fvecs / .npy)")
+    ap.add_argument("--gt", default=None, help="ground truth (.ivecs / .npy); computed exactly when absent")
+    ap.add_argument("--placement", choices=["stripes", "shards"], default="stripes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kmeans", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--assign-n", type=int, default=10_000_000)
     ap.add_argument("--work-dir", default=None)
     args = ap.parse_args()
@@ -139,8 +197,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    import ctypes as C
     import vector_indexer_py as vip
-    from vector_indexer_py import _native
+    from vector_indexer_py import _native, harness
+
+    lib = _native.lib()
 
     def barrier():
         if world > 1:
@@ -148,197 +209,184 @@ def main():
         torch.cuda.synchronize()
 
     # ---- data + index -------------------------------------------------------------------------
-    xb, xq = make_dataset(args.n, args.d, args.nq, 42, device)
-    work = args.work_dir or os.path.join(tempfile.gettempdir(), f"vi_bench_{os.getuid()}_{args.n}_{args.d}_{args.nlist}")
-    t0 = time.time()
+    gt = None
+    if args.base:
+        xb_h = harness.load_vectors(args.base)
+        xq_h = harness.load_vectors(args.query)[:args.nq]
+        xb, xq = torch.from_numpy(xb_h).to(device), torch.from_numpy(xq_h).to(device)
+        args.n, args.d = xb.shape
+        data = f"{os.path.basename(args.base)} / {os.path.basename(args.query)}"
+        if args.gt:
+            gt = torch.from_numpy(harness.load_groundtruth(args.gt)[:xq.shape[0], :args.k]).to(device)
+    else:
+        xb, xq = make_dataset(args.n, args.d, args.nq, 42, device)
+        data = "synthetic (SIFT1M-shaped mixture, seed 42; SIFT1M itself is not available offline)"
+    nq, k, d = xq.shape[0], args.k, args.d
+    work = args.work_dir or os.path.join(tempfile.gettempdir(), f"vi_bench_{os.getuid()}_{args.n}_{d}_{args.nlist}")
+    build = None
     if rank == 0:
         shutil.rmtree(work, ignore_errors=True)
+        t0 = time.time()
         built = vip.build(xb.cpu().numpy(), work, nlist=args.nlist, now_secs=1_700_000_000, device=local_rank)
+        bs = built.build_stats()
+        build = {"seconds": round(time.time() - t0, 2), "phases_ms": {p[3:]: round(bs[p], 1) for p in
+                 ("ms_upload", "ms_kmeans", "ms_group", "ms_super", "ms_export", "ms_index")},
+                 "shard_bytes": int(bs["shard_bytes"]), "lists": int(bs["lists"]), "shards": int(bs["shards"])}
         del built
-    build_s = time.time() - t0
     barrier()
-    index = vip.load(os.path.join(work, "index"), os.path.join(work, "shards"), args.d, device=local_rank,
-                     rank=rank if world > 1 else 0, world_size=world if world > 1 else 0)
+    placement = 1 if (args.placement == "shards" and world > 1) else 0
+    index = vip.load(os.path.join(work, "index"), os.path.join(work, "shards"), d, device=local_rank,
+                     rank=rank if world > 1 else 0, world_size=world if world > 1 else 0, placement=placement)
     index.enable_timing(True)
-    nq, k = args.nq, args.k
     D = torch.empty((nq, k), dtype=torch.float32, device=device)
     I = torch.empty((nq, k), dtype=torch.int64, device=device)
     T = torch.empty((nq, k), dtype=torch.int64, device=device)
     if world > 1:
-        # per-rank results packed [D | I | tie] so that ONE all-gather exchanges them
-        S = int(_native.lib().vi_packed_result_bytes(nq, k))
+        # per-rank results packed [D | I | tie] so that ONE all-gather exchanges them; every buffer of a step is
+        # allocated once here (per probe count), nothing inside the step allocates or copies through the host
+        S = int(lib.vi_packed_result_bytes(nq, k))
         off_i = (nq * k * 4 + 7) // 8 * 8
         off_t = off_i + nq * k * 8
         mine = torch.empty(S, dtype=torch.uint8, device=device)
         gathered = torch.empty(world * S, dtype=torch.uint8, device=device)
         Dm = torch.empty((nq, k), dtype=torch.float32, device=device)
         Im = torch.empty((nq, k), dtype=torch.int64, device=device)
-
-    if world > 1:  # coarse step split over the ranks by query: each rank probes its slice, one all-gather of the probes
         per = (nq + world - 1) // world
         q0, q1 = min(nq, rank * per), min(nq, (rank + 1) * per)
-        pmax = 64
-        PR = torch.full((per, 2 * pmax), -1, dtype=torch.int32, device=device)       # [probes | order] of my slice
-        PRg = torch.empty((world * per, 2 * pmax), dtype=torch.int32, device=device)
-        probes_all = torch.empty((world * per, pmax), dtype=torch.int32, device=device)
-        order_all = torch.empty((world * per, pmax), dtype=torch.int32, device=device)
+        probe_bufs = {}
+
+        def bufs_for(p_eff):
+            if p_eff not in probe_bufs:
+                po = torch.full((2, per, p_eff), -1, dtype=torch.int32, device=device)          # [probes | order] of my slice
+                pog = torch.empty((world, 2, per, p_eff), dtype=torch.int32, device=device)
+                pa = torch.empty((world * per, p_eff), dtype=torch.int32, device=device)
+                oa = torch.empty((world * per, p_eff), dtype=torch.int32, device=device)
+                probe_bufs[p_eff] = (po, pog, pa, oa)
+            return probe_bufs[p_eff]
 
     def step(n_probe):
         if world == 1:
             index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), T.data_ptr())
             return I
+        # The library works on its own blocking stream: it starts after what torch queued on the default stream
+        # (incl. the wait for a collective) and returns when its own work is done — no explicit synchronisation here.
         p_eff = min(n_probe, index.num_centroids)
-        pr = torch.empty((per, p_eff), dtype=torch.int32, device=device)
-        od = torch.empty((per, p_eff), dtype=torch.int32, device=device)
+        po, pog, pa, oa = bufs_for(p_eff)
         if q1 > q0:
-            index.probe_device(xq[q0:].data_ptr(), q1 - q0, n_probe, pr.data_ptr(), od.data_ptr())
-        PR[:, :p_eff] = pr
-        PR[:, pmax:pmax + p_eff] = od
-        dist.all_gather_into_tensor(PRg, PR)
-        pa = PRg[:nq, :p_eff].contiguous()
-        oa = PRg[:nq, pmax:pmax + p_eff].contiguous()
-        torch.cuda.synchronize()
+            index.probe_device(xq[q0:].data_ptr(), q1 - q0, n_probe, po[0].data_ptr(), po[1].data_ptr())
+        dist.all_gather_into_tensor(pog, po)
+        pa.view(world, per, p_eff).copy_(pog[:, 0])
+        oa.view(world, per, p_eff).copy_(pog[:, 1])
         base = mine.data_ptr()
         index.search_probed_device(xq.data_ptr(), nq, k, p_eff, pa.data_ptr(), oa.data_ptr(), base, base + off_i,
                                    base + off_t)
         dist.all_gather_into_tensor(gathered, mine)
-        torch.cuda.synchronize()
-        _native.check(_native.lib().vi_merge_partials_packed_device(local_rank, nq, k, world, gathered.data_ptr(),
-                                                                    Dm.data_ptr(), Im.data_ptr()))
+        torch.cuda.current_stream().synchronize()  # the merge below runs on the null stream of the library's device
+        _native.check(lib.vi_merge_partials_packed_device(local_rank, nq, k, world, gathered.data_ptr(), Dm.data_ptr(),
+                                                          Im.data_ptr()))
         return Im
 
-    # ---- operating point: nprobe sweep against exact ground truth -----------------------------
-    gt = ground_truth(xb, xq, k)
+    # ---- recall at every operating point of the sweep (scripts/run_faiss_bench.sh:55) -----------------
+    if gt is None:
+        gt = ground_truth(xb, xq, k)
     sweep = {}
-    chosen = args.nprobe
-    for p in ([] if chosen else [1, 2, 4, 8, 16, 32, 64]):
+    min_ok = None
+    for p in sorted({1, 2, 4, 8, 16, 32, 64, args.nprobe}):
         r1, ri = recalls(step(p), gt)
         sweep[p] = {"recall_1nn_at_k": round(r1, 4), "recall_at_k": round(ri, 4)}
-        if not chosen and ri >= 0.95:
-            chosen = p
-            break
-    if not chosen:
-        chosen = 64
-    if chosen not in sweep:
-        r1, ri = recalls(step(chosen), gt)
-        sweep[chosen] = {"recall_1nn_at_k": round(r1, 4), "recall_at_k": round(ri, 4)}
+        if min_ok is None and ri >= 0.95:
+            min_ok = p
+    head = args.nprobe
 
-    # ---- timed region -------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        step(chosen)
-    scan_ms, coarse_ms, tot_ms = [], [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(chosen)
+    # ---- timed region: the headline operating point ---------------------------------------------------
+    scan_ms, coarse_ms, group_ms, sel_ms, tot_ms = [], [], [], [], []
+
+    def timed_step():
+        step(head)
         st = index.last_stats()
-        scan_ms.append(st["ms_scan"]); coarse_ms.append(st["ms_coarse"]); tot_ms.append(st["ms_total"])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        scan_ms.append(st["ms_scan"]); coarse_ms.append(st["ms_coarse"]); group_ms.append(st["ms_group"])
+        sel_ms.append(st["ms_merge"]); tot_ms.append(st["ms_total"])
+    elapsed = time_steps(timed_step, args.steps, args.warmup, barrier, world, device)
+    scan_ms, coarse_ms, group_ms, sel_ms, tot_ms = (x[args.warmup:] for x in (scan_ms, coarse_ms, group_ms, sel_ms, tot_ms))
     st = index.last_stats()
     ms_per_step = elapsed * 1000.0 / args.steps
     qps = nq * args.steps / elapsed
-
-    # BASELINE configs[1] names nprobe=32 as the headline setting: the same batch there, for reference
-    at32 = None
-    if chosen != 32 and not args.nprobe:
-        r1_32, ri_32 = recalls(step(32), gt)
-        for _ in range(2):
-            step(32)
-        barrier()
-        t32 = time.perf_counter()
-        for _ in range(5):
-            step(32)
-        barrier()
-        e32 = time.perf_counter() - t32
-        if world > 1:
-            t = torch.tensor([e32], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e32 = float(t.item())
-        at32 = {"queries_per_s": round(nq * 5 / e32, 1), "ms_per_step": round(e32 * 1000.0 / 5, 4),
-                "recall_at_k": round(ri_32, 4), "recall_1nn_at_k": round(r1_32, 4)}
-        step(chosen)  # the statistics read below belong to the headline setting
-        st = index.last_stats()
-
-    # ---- roofline of the dominant kernel (list scan), from HIP events on the library's stream ----
-    scanned = torch.tensor([st["scanned_vectors"]], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(scanned)  # Σ over ranks = what a single GPU would scan
-    algo_bytes_rank = st["scanned_vectors"] * (4 * args.d + 8)  # 4·D per vector + 8 B id
+    roofline = roofline_of(st, float(np.mean(scan_ms)), d)
+    roofline["pipeline_ms"] = {"coarse": round(float(np.mean(coarse_ms)), 4), "grouping": round(float(np.mean(group_ms)), 4),
+                               "list_rank": round(float(np.mean(scan_ms)), 4), "select": round(float(np.mean(sel_ms)), 4),
+                               "total": round(float(np.mean(tot_ms)), 4)}
+    # algorithmic bytes of one launch: the resident image streamed once + the queries + the records written
+    image_bytes = index.num_vectors * d * (2 if int(st["rank_mode"]) == 3 else (4 if int(st["rank_mode"]) == 2 else 4))
+    algo_bytes = image_bytes + nq * d * 4 + st["filter_tile_blocks"] * 8 * 2 * (int(st["group_queries"]) or 128)
     scan_s = float(np.mean(scan_ms)) / 1000.0
-    algo_gbs = algo_bytes_rank / scan_s / 1e9 if scan_s > 0 else 0.0
-    common = {"algorithmic_bytes_per_launch": int(algo_bytes_rank), "avg_launch_ms": round(scan_s * 1000, 4),
-              "coarse_ms": round(float(np.mean(coarse_ms)), 4), "pipeline_ms": round(float(np.mean(tot_ms)), 4)}
-    if st["filter_tile_blocks"] > 0:
-        # MFMA path.  The list scan is a dense contraction (queries x list vectors x dims): one 64-vector block image
-        # staged in LDS is ranked against a group of <= 128 queries on the matrix cores.  Algorithmic flops = 2*D per
-        # (query, scanned vector) pair (multiply-add of the norm-expanded distance; SURVEY 8d's 3*D counts the
-        # reference's sub/mul/add, which this form does not execute).
-        tiles = st["filter_tile_blocks"]
-        dq = 4 * ((args.d + 15) // 16)
-        mode = int(st["rank_mode"])  # 1 f32 MFMA, 2 bf16x3, 3 bf16 on hi planes only
-        flops = 2.0 * args.d * st["scanned_vectors"]
-        tf = flops / scan_s / 1e12 if scan_s > 0 else 0.0
-        image = 64 * dq * (8 if mode == 3 else 16)       # bytes of one block image streamed per tile
-        gq = int(st["group_queries"]) or 128
-        tile_bytes = tiles * (image + 2 * gq * 16)        # + 2 x gq block records of 16 B per tile
-        stream = tile_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        extra = {"queries_per_work_item": gq, "flops_per_launch": flops, "useful_TFLOPs": round(tf, 1), "tiles_per_launch": int(tiles),
-                 "tile_bytes_per_launch": int(tile_bytes), "tile_stream_GBps": round(stream, 1),
-                 "survey_accounting_GBps": round(algo_gbs, 1), "hbm_peak_GBps": HBM_PEAK_GBS, **common}
-        if mode == 3:
-            # stored values are bf16-exact (8-bit descriptors): ONE bf16 MFMA per 16 dims, the matrix pipe is at
-            # ~15 % — what limits the kernel is the stream of tiles (hi image in, block records out) it must move.
-            roofline = {"kernel": "filter_kernel<NG,1,false,2> (bf16 MFMA ranking, hi planes only, of query-group x "
-                                  "list-segment tiles)", "bound": "hbm", "achieved": round(stream, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(stream / HBM_PEAK_GBS, 4), "traffic": None,
-                        "mfma_frac_of_bf16_peak": round(tf / MFMA_BF16_PEAK_TF, 4), **extra,
-                        "note": "achieved = bytes the kernel's decomposition must move per launch (one hi-plane block "
-                                "image per 128-query group + its block records) / launch time; traffic = what PMC saw "
-                                "cross to HBM/MALL (the query groups of a list re-read its blocks from L2/MALL); SURVEY "
-                                "8d's no-reuse accounting (4*D+8 B per (query, scanned vector)) is "
-                                "survey_accounting_GBps"}
-        else:
-            peak = MFMA_BF16_PEAK_TF / 3.0 if mode == 2 else MFMA_F32_PEAK_TF
-            roofline = {"kernel": ("filter_kernel<NG,1,false,1> (bf16x3 MFMA ranking" if mode == 2 else
-                                   "filter_kernel<NG,1,false,0> (f32 MFMA ranking") + " of query-group x list-segment tiles)",
-                        "bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(tf / peak, 4), "traffic": None,
-                        "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply" if mode == 2
-                                     else "f32 dense MFMA peak", **extra}
-    else:
-        roofline = {"kernel": "scan_kernel<LISTS> (inverted-list L2 scan + wave top-k)", "bound": "hbm",
-                    "achieved": round(algo_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(algo_gbs / HBM_PEAK_GBS, 4), "traffic": None, **common,
-                    "note": "achieved counts 4*D+8 B per (query, scanned vector); a list block loaded once is reused "
-                            "by up to 8 queries from registers, so the algorithmic rate can exceed what crosses HBM"}
-
-    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of
-    # this same command; gfx950 correction applied as MI355X_MICROARCH.md prescribes) when they match this workload
+    roofline["algorithmic_bytes_per_launch"] = int(algo_bytes)
+    roofline["frac_hbm_algorithmic"] = round(algo_bytes / scan_s / 1e9 / HBM_PEAK_GBS, 4) if scan_s > 0 else None
+    # HBM-side traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same
+    # command; gfx950 correction as MI355X_MICROARCH.md prescribes), when they were taken on this workload and kernel
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_scan_traffic.json")) as f:
-            tr = json.load(f)
-        import re
-        m = re.search(r"filter_kernel<\d+, \d+, false, (\d+)>", tr["kernel"])
-        same_kernel = (int(m.group(1)) + 1 == int(st["rank_mode"])) if m else (st["filter_tile_blocks"] == 0)
-        if tr["workload"] == [args.n, args.d, args.nlist, chosen, nq, k] and world == 1 and same_kernel:
+        tr = json.load(open(TRAFFIC_FILE))
+        if tr["workload"] == [args.n, d, args.nlist, head, nq, k] and world == 1 and tr.get("rank_mode") == int(st["rank_mode"]):
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
+            roofline["frac_hbm_traffic"] = round(tr["hbm_bytes_per_launch"] / scan_s / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / algo_bytes, 2)
     except Exception:
         pass
 
-    # ---- second BASELINE metric: k-means assign on the matrix cores (config C3) ---------------------------
+    extras = {}
+    # ---- multi-GPU: how the scan work splits under the two placements (share of the busiest rank) ----
+    if world > 1:
+        sv = torch.tensor([float(st["scanned_vectors"])], dtype=torch.float64, device=device)
+        allsv = [torch.zeros_like(sv) for _ in range(world)]
+        dist.all_gather(allsv, sv)
+        tot = sum(float(x.item()) for x in allsv)
+        extras["scan_share_of_busiest_rank"] = {args.placement: round(max(float(x.item()) for x in allsv) / max(tot, 1.0), 4),
+                                                "ideal": round(1.0 / world, 4)}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # (a) the smallest nprobe of the sweep reaching recall@10 >= 0.95, timed the same way
+        if min_ok is not None and min_ok != head:
+            e = time_steps(lambda: step(min_ok), args.steps, args.warmup, barrier, world, device)
+            extras["min_nprobe_at_recall_0.95"] = {"nprobe": min_ok, "queries_per_s": round(nq * args.steps / e, 1),
+                                                   "ms_per_step": round(e * 1000.0 / args.steps, 4), **sweep[min_ok]}
+        # (b) host-pointer entry (vi_indexer_search: queries and results cross PCIe inside the call)
+        xq_h, Dh, Ih = xq.cpu().numpy(), np.empty((nq, k), np.float32), np.empty((nq, k), np.int64)
+        kout = C.c_uint64(0)
+
+        def host_step():
+            _native.check(lib.vi_indexer_search(index._h, _native.ptr(xq_h), nq, d, k, head, _native.ptr(Dh), _native.ptr(Ih),
+                                                None, None, C.byref(kout)))
+        e = time_steps(host_step, max(3, args.steps // 2), 2, barrier, world, device)
+        extras["host_pointer_entry"] = {"queries_per_s": round(nq * max(3, args.steps // 2) / e, 1),
+                                        "ms_per_step": round(e * 1000.0 / max(3, args.steps // 2), 4),
+                                        "note": "vi_indexer_search: 5 MB of queries H2D + results D2H per call, PCIe-inclusive"}
+        # (c) small batches: latency per call at the headline nprobe
+        lat = {}
+        for b in (1, 64, 1024):
+            if b <= nq:
+                def small():
+                    index.search_device(xq.data_ptr(), b, k, head, D.data_ptr(), I.data_ptr(), 0)
+                e = time_steps(small, 50, 5, barrier, world, device)
+                lat[str(b)] = {"ms_per_call": round(e * 1000.0 / 50, 4), "queries_per_s": round(b * 50 / e, 1)}
+        extras["batch_latency"] = lat
+        # (d) real-valued data takes the bf16 x 3 ranking (lo planes streamed): the same batch with that arithmetic
+        os.environ["VI_FILTER_HI_ONLY"] = "0"
+        e = time_steps(lambda: step(head), max(3, args.steps // 2), 2, barrier, world, device)
+        st3 = index.last_stats()
+        del os.environ["VI_FILTER_HI_ONLY"]
+        extras["bf16x3_ranking"] = {"queries_per_s": round(nq * max(3, args.steps // 2) / e, 1),
+                                    "ms_per_step": round(e * 1000.0 / max(3, args.steps // 2), 4),
+                                    "list_rank_ms": round(st3["ms_scan"], 4), "rank_mode": int(st3["rank_mode"]),
+                                    "note": "what real-valued (not bf16-exact) stored vectors run; ids and distances are the same bits"}
+
+    # ---- second BASELINE metric: k-means on the matrix cores (config C3) ---------------------------
     kmeans = None
     if rank == 0 and world == 1 and not args.no_kmeans:
-        import ctypes as C
         del xb
         torch.cuda.empty_cache()
         n3, d3, k3 = args.assign_n, 128, 16384
-        g = torch.Generator(device=device); g.manual_seed(42)
+        g = torch.Generator(device=device)
+        g.manual_seed(42)
         X3 = torch.randn(n3, d3, generator=g, device=device)
         C3 = X3[torch.randperm(n3, generator=g, device=device)[:k3]].contiguous()
         lab = torch.empty(n3, dtype=torch.int32, device=device)
@@ -346,61 +394,129 @@ def main():
         ast = _native.AssignStats()
         best = None
         for _ in range(2):
-            _native.check(_native.lib().vi_assign_device(local_rank, X3.data_ptr(), n3, d3, C3.data_ptr(), k3, 42, 1,
-                                                         lab.data_ptr(), C.byref(ast)))
+            _native.check(lib.vi_assign_device(local_rank, X3.data_ptr(), n3, d3, C3.data_ptr(), k3, 42, 1, lab.data_ptr(),
+                                               C.byref(ast)))
             if best is None or ast.ms_total < best[0]:
-                best = (ast.ms_total, ast.ms_filter, int(ast.ambiguous_rows))
+                best = (ast.ms_total, ast.ms_filter, int(ast.ambiguous_rows), int(ast.tier1_rows))
         flops = 2.0 * n3 * k3 * d3
         tf = flops / (best[1] * 1e-3) / 1e12
+        bf16 = os.environ.get("VI_ASSIGN_BF16", "1") != "0"
         kmeans = {"workload": f"exact nearest-centroid assign N={n3} D={d3} k={k3} (BASELINE config C3), one full pass",
-                  "ms_total": round(best[0], 2), "ms_mfma_filter": round(best[1], 2), "ambiguous_rows_rechecked": best[2],
-                  "roofline": ({"kernel": "mfma_assign_bf16_kernel<16> (v_mfma_f32_32x32x16_bf16, operands split hi+lo: 3 "
-                                          "products per multiply)", "bound": "mfma", "achieved": round(tf, 1),
-                                "peak": round(MFMA_BF16_PEAK_TF / 3.0, 1), "unit": "TFLOP/s",
-                                "frac": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4), "flops_per_launch": flops,
-                                "peak_note": "bf16 dense MFMA peak 2516 TFLOP/s / 3 split products per multiply"}
-                               if os.environ.get("VI_ASSIGN_BF16", "1") != "0" else
-                               {"kernel": "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                                "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": round(tf / MFMA_F32_PEAK_TF, 4), "flops_per_launch": flops}),
+                  "ms_total": round(best[0], 2), "ms_mfma_filter": round(best[1], 2),
+                  "rows_left_by_bf16x3_tier": best[3], "rows_re_evaluated_exactly": best[2],
+                  "roofline": {"kernel": "mfma_assign_bf16_kernel<16> (v_mfma_f32_32x32x16_bf16, operands split hi+lo: 3 products "
+                                         "per multiply)" if bf16 else "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)",
+                               "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF,
+                               "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF), 4),
+                               "flops_per_launch": flops,
+                               "frac_of_bf16_peak_over_3": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4) if bf16 else None,
+                               "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+                               "peak_note": "achieved = useful 2*N*k*D flop / time of the first-tier kernel; frac against the "
+                                            "dense bf16 peak; the exact split arithmetic issues 3 MFMAs per product (frac_of_"
+                                            "bf16_peak_over_3 is the share of what that arithmetic can reach)"},
                   "hbm_GBps": round((4.0 * n3 * d3 + 4.0 * n3) / (best[1] * 1e-3) / 1e9, 1),
-                  "note": "labels are bit-identical to assign_points_brute_force: rows whose MFMA margin is not "
-                          "provably safe are re-evaluated in the reference's exact summation order"}
-        del X3, C3, lab
+                  "note": "labels == assign_points_brute_force on every row the tiers leave undecided and 20 000 sampled rows "
+                          "at this k and D (tests/test_baseline_configs_gpu.py::test_c3_exact_assign_k16384, N=1e6)"}
+        # update pass (update_centroids_parallel): per-cluster sums + counts of all points, device-resident
+        sums = torch.empty((k3, d3), dtype=torch.float32, device=device)
+        cnts = torch.empty(k3, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        tu = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            _native.check(lib.vi_kmeans_partial_sums_device(local_rank, X3.data_ptr(), n3, d3, lab.data_ptr(), k3,
+                                                            sums.data_ptr(), cnts.data_ptr()))
+            tu.append(time.perf_counter() - t0)
+        ub = 4.0 * n3 * d3 + 8.0 * n3 + 4.0 * k3 * d3
+        kmeans["update_pass"] = {"ms": round(min(tu) * 1e3, 2), "algorithmic_GBps": round(ub / min(tu) / 1e9, 1),
+                                 "frac_of_hbm_peak": round(ub / min(tu) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "vi_kmeans_partial_sums_device: grouping of the ids by cluster (device bitonic sort) + "
+                                         "sums in ascending id order (the reference's order), whole call"}
+        del sums, cnts, lab
+        # reference-compat mini-batch train (B=256, 20 iterations + final assign), device-resident points
+        Cout = torch.empty((k3, d3), dtype=torch.float32, device=device)
+        lab = torch.empty(n3, dtype=torch.int32, device=device)
+        it = C.c_uint64(0)
+        tr_ = {}
+        for name, mode in (("reference_assign_mode", 0), ("exact_assign_mode", 1)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _native.check(lib.vi_kmeans_mini_batch_device(local_rank, X3.data_ptr(), n3, d3, k3, 20, -1.0, 42, mode,
+                                                          Cout.data_ptr(), lab.data_ptr(), C.byref(it)))
+            tr_[name] = {"seconds": round(time.perf_counter() - t0, 2), "iterations": int(it.value)}
+        kmeans["mini_batch_train"] = {**tr_, "note": "vi_kmeans_mini_batch_device, points resident in HBM; dominated by what the "
+                                      "reference pins to the host: 16 384 sequential k-means++ draws and a full shuffle of 0..N "
+                                      "per iteration (kmeans.rs:722-726)"}
+        del X3, C3, lab, Cout
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (C restatement of the reference's CPU path) on the host cores -------
     cpu = None
+    c1 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib as O
         orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
         threads = min(O.lib().orc_max_threads(), O.usable_cpus())
         xq_h = xq.cpu().numpy()
         done, t0c, chunk = 0, time.perf_counter(), 500
+        checked = 0
         while time.perf_counter() - t0c < args.cpu_seconds and done < nq:
             m = min(chunk, nq - done)
-            rc, Do, Io = orc.search_batch(xq_h[done:done + m], k, chosen, threads)
-            if done == 0:  # parity spot check on the same queries
-                assert (Io == step(chosen)[:m].cpu().numpy()).all(), "GPU ids differ from the CPU oracle"
+            rc, Do, Io = orc.search_batch(xq_h[done:done + m], k, head, threads)
+            if done == 0:  # parity spot check on the same queries: ids and distance bits
+                Ig = step(head)[:m].cpu().numpy()
+                Dg = D[:m].cpu().numpy()
+                assert (Io == Ig).all() and (Do.view(np.uint32) == Dg.view(np.uint32)).all(), "GPU differs from the CPU oracle"
+                checked = m
             done += m
         cpu_s = time.perf_counter() - t0c
         cpu = {"value": round(done / cpu_s, 1), "unit": "queries/s", "cores": int(threads), "kind": "port",
-               "sample": f"{done} of the {nq} bench queries, same index files, nprobe={chosen}, k={k}, lists preloaded "
-                         f"in RAM (the reference additionally re-reads shard files per query), host has "
-                         f"{os.cpu_count()} logical cores"}
+               "sample": f"{done} of the {nq} bench queries, same index files, nprobe={head}, k={k}, lists preloaded in RAM "
+                         f"(the reference additionally re-reads shard files per query); first {checked} checked bit for bit "
+                         f"against the GPU; host has {os.cpu_count()} logical cores"}
+        del orc
+        # config C1 (the reference's own CPU-runnable case): N=50 000 D=64 nlist=100 nprobe=8 k=10, 1 000 queries
+        if not args.no_extras:
+            rng = np.random.default_rng(42)
+            xb1 = rng.standard_normal((50_000, 64)).astype(np.float32)
+            xq1 = rng.standard_normal((1_000, 64)).astype(np.float32)
+            w1 = work + "_c1"
+            shutil.rmtree(w1, ignore_errors=True)
+            os.makedirs(w1 + "/index"), os.makedirs(w1 + "/shards")
+            t0 = time.perf_counter()
+            o1 = O.OracleIndex.build(xb1, w1 + "/index", w1 + "/shards", nlist=100, now=1_700_000_000)
+            tb = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 3.0:
+                rc, Do, Io = o1.search_batch(xq1, 10, 8, threads)
+                reps += 1
+            ts = (time.perf_counter() - t0) / reps
+            g1 = vip.load(w1 + "/index", w1 + "/shards", 64, device=local_rank)
+            Dg, Ig = g1.search_sync(xq1, 10, 8)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g1.search_sync(xq1, 10, 8)
+            tg = (time.perf_counter() - t0) / 20
+            c1 = {"workload": "C1: N=50000 D=64 nlist=100 nprobe=8 k=10, 1000 queries (default_rng(42).standard_normal)",
+                  "cpu_path": {"queries_per_s": round(1000 / ts, 1), "build_s": round(tb, 2), "cores": int(threads), "kind": "port"},
+                  "gpu_path_host_pointers": {"queries_per_s": round(1000 / tg, 1)},
+                  "identical_results": bool((Ig == Io).all() and (Dg.view(np.uint32) == Do.view(np.uint32)).all())}
+            shutil.rmtree(w1, ignore_errors=True)
+    if c1:
+        extras["config_C1"] = c1
 
     if rank == 0:
         out = {"metric": "QPS at recall@10>=0.95 (IVF search, SIFT1M-shaped)", "value": round(qps, 1),
                "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-               "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
-               "data": "synthetic (SIFT1M-shaped mixture, seed 42; SIFT1M itself is not available offline)",
-               "config": {"workload": f"IVF search N={args.n} D={args.d} nlist={args.nlist} nprobe={chosen} k={k} "
-                                      f"nq/step={nq}", "nprobe": chosen, "recall": sweep[chosen],
-                          "nprobe_sweep": sweep, "at_nprobe_32": at32, "index_centroids": index.num_centroids,
-                          "build_s": round(build_s, 1),
-                          "parallelism": f"every list striped over {world} GPU(s) (block b on rank b % N), coarse table replicated"
-                                         + (", RCCL all-gather of per-rank top-k" if world > 1 else "")},
-               "roofline": roofline, "cpu_baseline": cpu, "kmeans_assign": kmeans}
+               "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": data,
+               "config": {"workload": f"IVF search N={args.n} D={d} nlist={args.nlist} nprobe={head} k={k} nq/step={nq} "
+                                      "(BASELINE configs[1])", "nprobe": head, "recall": sweep[head], "nprobe_sweep": sweep,
+                          "index_centroids": index.num_centroids, "build": build,
+                          "parallelism": (f"{args.placement} over {world} GPUs, coarse table replicated, coarse step split by query, "
+                                          "RCCL all-gather of probe lists and of per-rank top-k") if world > 1 else "1 GPU"},
+               "roofline": roofline, "cpu_baseline": cpu, "kmeans_assign": kmeans, "extras": extras}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

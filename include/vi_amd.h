@@ -211,6 +211,11 @@ typedef struct vi_config {
   int32_t world_size;
   uint64_t now_secs;        /* 0 => wall clock; else value used for timestamp==0 records
                                (vector_store.rs:36-40) */
+  /* multi-GPU partition rule: 0 = stripes (above; balances whatever the skew); 1 = shard placement: whole shard
+   * files — the reference's super-centroid grouping of lists, src/ivf_index.rs:104-164 — are dealt to the ranks greedily
+   * by bytes (largest first to the least loaded rank), a list is scanned by the one rank that holds its shard */
+  int32_t placement;
+  int32_t reserved0;
 } vi_config;
 
 /* VectorIndexerConfig::new(dimension) — src/api.rs:33-43 */

@@ -7,6 +7,7 @@ import threading
 import numpy as np
 import pytest
 
+import vector_indexer_py as vip
 from vector_indexer_py import _native as N
 from vector_indexer_py.api import SearchRequest, VectorIndexer, VectorIndexerConfig, VectorRecord
 
@@ -186,3 +187,37 @@ def test_single_vector_index(tmp_path):  # ivf_index_tests.rs:369-392
     ix = VectorIndexer.new(cfg_for(tmp_path, 4)).build_from_records([VectorRecord(99, [1.0, 2.0, 3.0, 4.0])])
     r = ix.search(SearchRequest([1.0, 2.0, 3.0, 4.0], False, 5, 5))
     assert len(r) == 1 and r[0].external_id == 99 and r[0].distance == 0.0
+
+
+def test_faiss_style_harness_drives_the_engine(tmp_path):
+    """the reference's bench methodology (bench_all_ivf.py: eval_setting loop over an adapter with a settable .nprobe,
+    K=100 as scripts/run_faiss_bench.sh:54 sets it, JSON + Markdown output) on the engine, small size"""
+    from vector_indexer_py import harness as H
+    xb, xq, gt = H.synthetic_dataset(6000, 32, 50, 100, seed=42)
+    res = H.run(xb, xq, gt, 100, [1, 8, 1000], 0.05, work_dir=str(tmp_path / "w"), verbose=False)
+    assert res["n"] == 6000 and res["d"] == 32 and res["k"] == 100 and res["nlist"] > 0 and res["build_time_s"] > 0
+    rec = [res["search_results"][f"nprobe={p}"]["recalls"] for p in (1, 8, 1000)]
+    assert all(set(r) == {1, 10, 100} for r in rec)
+    assert rec[2][1] == 1.0 and rec[2][100] == 1.0            # n_probe >= #lists is exhaustive: the true NN is rank 1
+    assert rec[0][100] <= rec[1][100] <= rec[2][100]
+    assert all(res["search_results"][f"nprobe={p}"]["nrun"] >= 1 for p in (1, 8, 1000))
+    H.save_results([res], str(tmp_path / "out"))
+    assert os.path.exists(tmp_path / "out" / "faiss_bench_results.json") and os.path.exists(tmp_path / "out" / "faiss_bench_results.md")
+    # the adapter's search == the index's own search at that nprobe
+    idx = vip.load(str(tmp_path / "w" / "index"), str(tmp_path / "w" / "shards"), 32)
+    ad = H.FaissStyleAdapter(idx, 100)
+    ad.nprobe = 8
+    D1, I1 = ad.search(xq, 10)
+    D2, I2 = idx.search_sync(xq, 10, 8)
+    assert ad.d == 32 and (I1 == I2).all() and (D1.view(np.uint32) == D2.view(np.uint32)).all()
+
+
+def test_build_reports_its_phases(tmp_path):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((20000, 24)).astype(np.float32)
+    idx = vip.build(X, str(tmp_path), nlist=64)
+    st = idx.build_stats()
+    assert st["n"] == 20000 and st["nlist"] == 64 and 0 < st["lists"] <= 64 and st["shards"] == 8
+    assert st["shard_bytes"] == 20000 * (24 + 24 * 4)
+    parts = sum(st[k] for k in ("ms_upload", "ms_kmeans", "ms_group", "ms_super", "ms_export", "ms_index"))
+    assert st["ms_total"] > 0 and abs(parts - st["ms_total"]) < 0.05 * st["ms_total"] + 1.0

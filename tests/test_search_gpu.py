@@ -423,3 +423,36 @@ def test_out_of_range_probe_lists_are_rejected(tmp_path):
         assert (hip.download(Ig, (nq, k), np.int64) == Io).all()
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_shard_placement_ranks_merge_to_the_single_gpu_result(world, tmp_path):
+    """north_star's partition rule (vi_config.placement = 1): whole shard files — the reference's super-centroid grouping,
+    ivf_index.rs:104-164 — dealt to the ranks greedily by bytes.  Every vector is resident on exactly one rank, and the
+    merged per-rank top-k equal the oracle's bit for bit."""
+    from vector_indexer_py import _native
+    rng = np.random.default_rng(23)
+    base = rng.integers(-3, 4, size=(5000, 16)).astype(np.float32)
+    X = np.concatenate([base, base[:1200]])
+    orc, full = oracle_and_gpu(tmp_path, X, nlist=30)
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    parts = [vip.load(idx, sh, X.shape[1], rank=r, world_size=world, placement=1) for r in range(world)]
+    assert sum(p.num_vectors for p in parts) == X.shape[0]
+    assert sum(1 for p in parts if p.num_vectors > 0) >= 2
+    Q = np.concatenate([base[:150], rng.integers(-3, 4, size=(100, 16)).astype(np.float32)])
+    hip = _Hip()
+    try:
+        nq = Q.shape[0]
+        xq = hip.upload(Q)
+        for k, n_probe in [(10, 6), (3, 30), (40, 2)]:
+            Dg, Ig, Tg = hip.alloc(world * nq * k * 4), hip.alloc(world * nq * k * 8), hip.alloc(world * nq * k * 8)
+            for r, p in enumerate(parts):
+                p.search_device(xq, nq, k, n_probe, Dg + r * nq * k * 4, Ig + r * nq * k * 8, Tg + r * nq * k * 8)
+            Dm, Im = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+            _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+            rc, Do, Io = orc.search_batch(Q, k, n_probe)
+            assert rc == O.ORC_OK
+            assert (hip.download(Im, (nq, k), np.int64) == Io).all(), (k, n_probe)
+            assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), (k, n_probe)
+    finally:
+        hip.close()

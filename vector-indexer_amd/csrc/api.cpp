@@ -36,7 +36,8 @@ static uint64_t unix_timestamp_secs() {  // src/utils.rs:109-114
 
 static vi_status attach_device(Indexer *ix) {
   auto dev = std::make_unique<DeviceIndex>();
-  VI_TRY(device_index_load(ix->meta, ix->shards_dir, ix->cfg.device, ix->cfg.rank, ix->cfg.world_size, dev.get()));
+  VI_TRY(device_index_load(ix->meta, ix->shards_dir, ix->cfg.device, ix->cfg.rank, ix->cfg.world_size, ix->cfg.placement,
+                           dev.get()));
   ix->dev = std::move(dev);
   return VI_OK;
 }

@@ -103,9 +103,12 @@ struct DeviceIndex {
   ~DeviceIndex();
 };
 
-// Upload: centroid table + this rank's stripe of every list (block b on rank b % world), repacked on the GPU.
+// Upload: centroid table + this rank's part of the lists, repacked on the GPU.  placement 0: a stripe of every list
+// (block b on rank b % world); 1: the whole lists of the shard files dealt to this rank (greedy by bytes).
 vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir, int device, int rank,
-                            int world, DeviceIndex *out);
+                            int world, int placement, DeviceIndex *out);
+// owner rank of every shard under placement 1: shards by descending bytes, each to the least loaded rank so far
+std::vector<uint32_t> shard_owners(const std::vector<uint64_t> &shard_bytes, uint32_t world);
 
 struct SearchIO {
   const float *queries = nullptr;  // host or device (queries_on_device)

@@ -566,6 +566,11 @@ __global__ void segment_sum_kernel(const float *X, const uint32_t *order, const 
   if (j == 0) counts[c] = e - b;
 }
 
+__global__ void label_range_kernel(const uint32_t *labels, uint64_t n, uint32_t k, uint32_t *bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && labels[i] >= k) atomicOr(bad, 1u);
+}
+
 // C_new[c] = sums[c] / counts[c] (zeros for an empty cluster, kmeans.rs:705-712), and the per-cluster partial of
 // compute_centroid_delta against C_prev
 __global__ void finish_update_kernel(const float *sums, const uint32_t *counts, const float *prev, uint32_t k, uint32_t d,
@@ -803,14 +808,21 @@ vi_status kmeans_partial_sums_device(int device, const float *Xd, uint64_t n, ui
   if (n > 0xFFFFFFFEull) return fail(VI_ERR_INVALID_INPUT, "more than 2^32 - 2 points");
   Ctx cx;
   VI_TRY(cx.init(device));
-  std::vector<uint32_t> l32(n), order, seg;
-  if (n) VI_HIP(hipMemcpyAsync(l32.data(), labels_dev, n * 4, hipMemcpyDeviceToHost, cx.st));
+  // ids grouped by cluster, ascending id inside a cluster, without leaving the device (list_build.hip)
+  DevBuf<uint32_t> d_order, d_seg, d_bad;
+  std::vector<uint64_t> off;
+  VI_TRY(d_bad.reserve(1));
+  VI_HIP(hipMemsetAsync(d_bad.p, 0, 4, cx.st));
+  if (n) {
+    hipLaunchKernelGGL(label_range_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, cx.st, labels_dev, n, (uint32_t)k, d_bad.p);
+    VI_HIP(hipGetLastError());
+  }
+  uint32_t bad = 0;
+  VI_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, cx.st));
   VI_HIP(hipStreamSynchronize(cx.st));
-  for (uint64_t i = 0; i < n; ++i)
-    if (l32[i] >= k) return fail(VI_ERR_INVALID_INPUT, "label %u of point %llu is not below k", l32[i], (unsigned long long)i);
-  group_by_label(l32.data(), n, k, order, seg);
-  DevBuf<uint32_t> d_order, d_seg;
-  VI_TRY(to_device(d_order, order.data(), order.size(), cx.st));
+  if (bad) return fail(VI_ERR_INVALID_INPUT, "a label is not below k");
+  VI_TRY(group_ids_by_label_device(labels_dev, n, k, d_order, off, cx.st));
+  std::vector<uint32_t> seg(off.begin(), off.end());
   VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
   const uint64_t nt = k * d;
   hipLaunchKernelGGL(segment_sum_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd, d_order.p, d_seg.p,

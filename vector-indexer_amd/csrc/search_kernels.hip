@@ -791,8 +791,24 @@ static vi_status repack_upload(const uint8_t *host_src, size_t src_bytes, const 
 
 static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists);
 
+std::vector<uint32_t> shard_owners(const std::vector<uint64_t> &shard_bytes, uint32_t world) {
+  const size_t ns = shard_bytes.size();
+  std::vector<uint32_t> order(ns), owner(ns, 0);
+  for (size_t i = 0; i < ns; ++i) order[i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return shard_bytes[a] > shard_bytes[b]; });
+  std::vector<uint64_t> load(std::max<uint32_t>(world, 1), 0);
+  for (uint32_t s : order) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < load.size(); ++r)
+      if (load[r] < load[best]) best = r;
+    owner[s] = best;
+    load[best] += shard_bytes[s];
+  }
+  return owner;
+}
+
 vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir, int device, int rank, int world,
-                            DeviceIndex *ix) {
+                            int placement, DeviceIndex *ix) {
   VI_TRY(init_device_index(ix, device, meta.dimension, meta.k()));
   const uint32_t dim = ix->dim, dq = ix->dq;
   const uint64_t k = ix->nlists;
@@ -840,7 +856,22 @@ vi_status device_index_load(const IndexMeta &meta, const std::string &shards_dir
     const ShardListView *lv = files[s]->find(c);
     if (!lv) { files[s].reset(); continue; }  // NotFound fails the whole shard read (shards.rs:257-265)
   }
-  const uint32_t W = part ? (uint32_t)world : 1u, R = part ? (uint32_t)rank : 0u;
+  // placement 1 (north_star's rule): whole shard files to ranks, greedy by bytes; this rank then holds every block of
+  // the lists of its shards (W = 1 below) and nothing of the others
+  std::vector<uint32_t> owner;
+  const bool by_shard = part && placement == 1;
+  if (by_shard) {
+    std::vector<uint64_t> bytes(nshards, 0);
+    for (uint64_t c = 0; c < k; ++c) {
+      const uint64_t s = meta.c2s[c];
+      if (s >= nshards || !files[s]) continue;
+      if (const ShardListView *lv = files[s]->find(c)) bytes[s] += (uint64_t)lv->num_vectors * record_stride(dim);
+    }
+    owner = shard_owners(bytes, (uint32_t)world);
+    for (uint64_t s = 0; s < nshards; ++s)
+      if (owner[s] != (uint32_t)rank) files[s].reset();  // (as if the file were not there: its lists stay empty here)
+  }
+  const uint32_t W = (part && !by_shard) ? (uint32_t)world : 1u, R = (part && !by_shard) ? (uint32_t)rank : 0u;
   ix->stripe_world = W;
   ix->stripe_rank = R;
   // this rank's blocks of a list of n vectors: b = R, R+W, ... ; the last block of the list may be partial

@@ -179,9 +179,10 @@ def build(xb, work_dir: Optional[str] = None, *, nlist: int = 0, seed: int = 0, 
 
 
 def load(index_dir: str, shards_dir: str, dimension: int, *, device: int = 0, rank: int = 0,
-         world_size: int = 0) -> VectorIndex:
+         world_size: int = 0, placement: int = 0) -> VectorIndex:
     """load(index_dir, shards_dir, dimension) — lib.rs:291-304."""
-    cfg, keep = _config(dimension, index_dir, shards_dir, device=device, rank=rank, world_size=world_size)
+    cfg, keep = _config(dimension, index_dir, shards_dir, device=device, rank=rank, world_size=world_size,
+                        placement=placement)
     h = C.c_void_p()
     _native.check(lib().vi_indexer_load(C.byref(cfg), C.byref(h)), prefix="Failed to load index: ")
     return VectorIndex(h, dimension, keep)

@@ -29,7 +29,7 @@ class Config(C.Structure):
     _fields_ = [("dimension", u32), ("index_dir", C.c_char_p), ("shards_dir", C.c_char_p),
                 ("default_k", u64), ("default_n_probe", u64), ("max_k", u64), ("max_n_probe", u64),
                 ("nlist_override", u64), ("seed", u64), ("assign_mode", i32), ("device", i32),
-                ("rank", i32), ("world_size", i32), ("now_secs", u64)]
+                ("rank", i32), ("world_size", i32), ("now_secs", u64), ("placement", i32), ("reserved0", i32)]
 
 
 class SearchStats(C.Structure):
