@@ -10,30 +10,32 @@ import json
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-workload = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1_000_000, 128, 4096, 16, 10_000, 10]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+workload = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1_000_000, 128, 4096, 32, 10_000, 10]
 kt = glob.glob(f"gpurun_out/prof_{tag}_kt/*/*_kernel_stats.csv")[0]
 shutil.copy(kt, f"profiles/{tag}_bench_kernel_stats.csv")
 
 
 # dominant kernel of the pipeline: the MFMA list ranking when the MFMA path ran, else the VALU list scan
-KERNEL = r"filter_kernel<\d+, \d+, false, \d+>|scan_kernel<\d+, 0, false, false>"
+KERNEL = r"filter_kernel<\d+, \d+, false, \d+, \d+>|scan_kernel<\d+, 0, false, false>"
 
 
 def scan_avg(pattern, counter):
     f = glob.glob(pattern)[0]
     rows = [r for r in csv.DictReader(open(f)) if re.search(KERNEL, r["Kernel_Name"])
             and r["Counter_Name"] == counter]
+    rows = [r for r in rows if r["Kernel_Name"] == rows[-1]["Kernel_Name"]]  # the timed steps' instantiation
     vals = [float(r["Counter_Value"]) for r in rows]
     vals = vals[-5:]  # the timed steps (same nprobe); earlier launches are warm-up / recall evaluation
-    return sum(vals) / len(vals), len(vals), rows[0]["Kernel_Name"]
+    return sum(vals) / len(vals), len(vals), rows[-1]["Kernel_Name"]
 
 
 fetch, n1, name = scan_avg(f"gpurun_out/prof_{tag}_fetch/*/*_counter_collection.csv", "FETCH_SIZE")
 write, n2, _ = scan_avg(f"gpurun_out/prof_{tag}_write/*/*_counter_collection.csv", "WRITE_SIZE")
 stats = {r["Name"]: r for r in csv.DictReader(open(kt))}
-scan = max((v for k, v in stats.items() if re.search(KERNEL, k)), key=lambda v: float(v["TotalDurationNs"]))
-out = {"workload": workload, "kernel": name, "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
+scan = stats[name]
+m = re.search(r"filter_kernel<\d+, \d+, false, (\d+), \d+>", name)
+out = {"workload": workload, "kernel": name, "rank_mode": (int(m.group(1)) + 1) if m else 0, "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
        "hbm_bytes_per_launch": int((2.0 * fetch + write) * 1024),
        "avg_launch_ns_rocprof": float(scan["AverageNs"]), "calls": int(scan["Calls"]),
        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --nprobe {workload[3]}`; "

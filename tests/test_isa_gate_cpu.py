@@ -1,0 +1,84 @@
+"""Build-time gate for the hand-placed waits of the double-buffered rank kernels (filter_search.hip, NBUF == 2).
+
+Their block loop issues the next tile's LDS-DMA as inline asm and ends with a counted `s_waitcnt vmcnt(1)` that is only
+correct if the wave's ONE younger vector-memory operation is its pair-record store.  A register spill (scratch traffic),
+a store the compiler splits in two or an extra global load inside the loop would be a second younger operation: the
+barrier would release before the DMA has landed, a silent LDS race no parity test is guaranteed to catch.  This test
+compiles the file to gfx950 assembly (no GPU needed) and checks exactly that, so a compiler or source change that
+breaks the assumption fails here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "vector-indexer_amd", "csrc", "filter_search.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("isa") / "filter_search.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"]
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", out, SRC], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def kernels(asm_text):
+    """name -> (body text, metadata dict) of every filter_kernel instantiation"""
+    out = {}
+    for m in re.finditer(r"^(_ZN2vi12_GLOBAL__N_113filter_kernelILi(\d+)ELi(\d)ELb([01])ELi(\d)ELi(\d+)EEEvNS0_10FilterArgsE):[^\n]*\n(.*?)\n\s*s_endpgm",
+                         asm_text, re.S | re.M):
+        name, ng, nbuf, table, rank, gq, body = m.groups()
+        meta = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(.*?)\.end_amdhsa_kernel", asm_text, re.S).group(1)
+        out[name] = dict(body=body, meta=meta, ng=int(ng), nbuf=int(nbuf), table=table == "1", rank=int(rank), gq=int(gq))
+    return out
+
+
+def block_loop(body):
+    """the instructions of the loop that holds the per-block s_barrier: LLVM marks a loop's header with
+    '=>This Inner Loop Header' / '=>This Loop Header' and its other blocks with 'in Loop: Header=<label>'"""
+    blocks, cur, label, note = {}, [], None, ""
+    for line in body.split("\n"):
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", line)
+        if m:
+            if label is not None:
+                blocks[label] = (note, "\n".join(cur))
+            label, note, cur = m.group(1), m.group(2) or "", []
+        elif label is not None:
+            cur.append(line)
+    if label is not None:
+        blocks[label] = (note, "\n".join(cur))
+    groups = {}
+    for lab, (note, text) in blocks.items():
+        h = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
+        if h:
+            groups.setdefault(".L" + h.group(1), []).append(text)
+        elif "Loop Header" in note:
+            groups.setdefault(lab, []).append(text)
+    with_barrier = [t for t in groups.values() if any("s_barrier" in x for x in t)]
+    assert len(with_barrier) == 1, "expected exactly one loop with a barrier"
+    return "\n".join(with_barrier[0])
+
+
+def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
+    ks = kernels(asm)
+    assert len(ks) >= 16
+    dbl = {n: k for n, k in ks.items() if k["nbuf"] == 2}
+    assert dbl, "no double-buffered instantiation found"
+    for name, k in ks.items():
+        priv = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", k["meta"]).group(1))
+        assert priv == 0, f"{name}: {priv} bytes of scratch (a spill is a vector-memory operation the waits do not count)"
+        assert not re.search(r"^\s*(scratch_|buffer_)", k["body"], re.M), name
+    for name, k in dbl.items():
+        loop = block_loop(k["body"])
+        stores = re.findall(r"^\s*global_store_\w+", loop, re.M)
+        assert stores == ["\tglobal_store_dwordx4"], f"{name}: stores in the block loop: {stores}"
+        loads = re.findall(r"^\s*global_load_(?!lds)\w+", loop, re.M)
+        assert not loads, f"{name}: plain global loads inside the block loop: {loads}"
+        assert re.search(r"global_load_lds_dwordx4", loop), name
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
+        assert "1" in waits and set(waits) <= {"0", "1"}, f"{name}: vmcnt waits {waits}"

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 #include "device_index.hpp"
@@ -27,6 +29,21 @@ struct Indexer {
   std::unique_ptr<DeviceIndex> dev;     // HBM-resident lists (null until load/build)
   vi_build_stats build_stats{};         // phases of the last build on this handle
 };
+
+// No C++ exception may unwind through the C ABI into a Rust / ctypes caller (std::vector growth, std::string, a
+// corrupt length field...): every extern "C" entry point that returns a status runs its body in here.
+template <typename F>
+static vi_status guarded(F &&body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(VI_ERR_OTHER, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(VI_ERR_OTHER, "internal error: %s", e.what());
+  } catch (...) {
+    return fail(VI_ERR_OTHER, "internal error");
+  }
+}
 
 static uint64_t unix_timestamp_secs() {  // src/utils.rs:109-114
   struct timeval tv;
@@ -205,79 +222,103 @@ uint64_t vi_minibatch_size(uint64_t n) {
 }
 
 vi_status vi_l2sq_pairs(const float *a, const float *b, uint64_t n, uint32_t d, vi_sum_order order, float *out) {
+  return vi::guarded([&]() -> vi_status {
   if ((n && (!a || !b || !out))) return fail(VI_ERR_INVALID_INPUT, "null pointer");
   return vi::l2sq_pairs_device(a, b, n, d, (int)order, out);
+  });
 }
 
 vi_status vi_assign(const float *X, uint64_t n, uint32_t d, const float *C, uint64_t k, uint64_t seed,
                     vi_assign_mode mode, uint64_t *labels, float *dist_out) {
+  return vi::guarded([&]() -> vi_status {
   if (n == 0) return VI_OK;
   if (!X || !C || !labels || d == 0 || k == 0) return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_assign");
   vi::KMeansOptions opt;
   opt.mode = mode;
   return vi::assign_points(X, n, d, C, k, seed, opt, labels, dist_out);
+  });
 }
 
 vi_status vi_assign_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, const float *C_dev, uint64_t k,
                            uint64_t seed, vi_assign_mode mode, uint32_t *labels_dev, vi_assign_stats *stats) {
+  return vi::guarded([&]() -> vi_status {
   if (n == 0) return VI_OK;
   if (!X_dev || !C_dev || !labels_dev || d == 0 || k == 0) return fail(VI_ERR_INVALID_INPUT, "bad arguments to vi_assign_device");
   return vi::assign_points_device(device, X_dev, n, d, C_dev, k, seed, mode, labels_dev, stats);
+  });
 }
 
 vi_status vi_kmeans_mini_batch(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
                                uint64_t seed, vi_assign_mode mode, float *C, uint64_t *labels, uint64_t *iters) {
+  return vi::guarded([&]() -> vi_status {
   vi::KMeansOptions opt;
   opt.mode = mode;
   return vi::kmeans_mini_batch(X, n, d, k, max_iters, thr, seed, opt, C, labels, iters);
+  });
 }
 
 vi_status vi_kmeans_parallel(const float *X, uint64_t n, uint32_t d, uint64_t k, uint64_t max_iters, float thr,
                              uint64_t seed, vi_assign_mode mode, float *C, uint64_t *labels, uint64_t *iters) {
+  return vi::guarded([&]() -> vi_status {
   vi::KMeansOptions opt;
   opt.mode = mode;
   return vi::kmeans_parallel(X, n, d, k, max_iters, thr, seed, opt, C, labels, iters);
+  });
 }
 
 vi_status vi_kmeans_mini_batch_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
                                       uint64_t max_iters, float thr, uint64_t seed, vi_assign_mode mode, float *C_dev,
                                       uint32_t *labels_dev, uint64_t *iters) {
+  return vi::guarded([&]() -> vi_status {
   return vi::kmeans_mini_batch_device(device, X_dev, n, d, k, max_iters, thr, seed, mode, C_dev, labels_dev, iters);
+  });
 }
 
 vi_status vi_kmeans_parallel_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d, uint64_t k,
                                     uint64_t max_iters, float thr, uint64_t seed, vi_assign_mode mode, float *C_dev,
                                     uint32_t *labels_dev, uint64_t *iters) {
+  return vi::guarded([&]() -> vi_status {
   return vi::kmeans_parallel_device(device, X_dev, n, d, k, max_iters, thr, seed, mode, C_dev, labels_dev, iters);
+  });
 }
 
 vi_status vi_kmeans_mini_batch_train(int32_t device, const vi_row_source *rows, uint64_t n, uint32_t d, uint64_t k,
                                      uint64_t max_iters, float thr, uint64_t seed, float *C_dev, uint64_t *iters) {
+  return vi::guarded([&]() -> vi_status {
   if (!rows) return fail(VI_ERR_INVALID_INPUT, "null row source");
   return vi::kmeans_mini_batch_train(device, *rows, n, d, k, max_iters, thr, seed, C_dev, iters);
+  });
 }
 
 vi_status vi_kmeans_pp_init(int32_t device, const vi_row_source *rows, uint64_t n, uint32_t d, uint64_t k, uint64_t seed,
                             float *C_dev) {
+  return vi::guarded([&]() -> vi_status {
   if (!rows) return fail(VI_ERR_INVALID_INPUT, "null row source");
   return vi::kmeans_pp_init_rows_entry(device, *rows, n, d, k, seed, C_dev);
+  });
 }
 
 vi_status vi_kmeans_partial_sums_device(int32_t device, const float *X_dev, uint64_t n, uint32_t d,
                                         const uint32_t *labels_dev, uint64_t k, float *sums_dev, uint32_t *counts_dev) {
+  return vi::guarded([&]() -> vi_status {
   return vi::kmeans_partial_sums_device(device, X_dev, n, d, labels_dev, k, sums_dev, counts_dev);
+  });
 }
 
 vi_status vi_kmeans_finish_update_device(int32_t device, const float *sums_dev, const uint32_t *counts_dev, uint64_t k,
                                          uint32_t d, const float *C_prev_dev, float *C_new_dev, float *delta_out,
                                          uint32_t *empty_out, uint64_t *n_empty) {
+  return vi::guarded([&]() -> vi_status {
   return vi::kmeans_finish_update_device(device, sums_dev, counts_dev, k, d, C_prev_dev, C_new_dev, delta_out, empty_out,
                                          n_empty);
+  });
 }
 
 vi_status vi_kmeans_centroid_delta_device(int32_t device, const float *C_new_dev, const float *C_prev_dev, uint64_t k,
                                           uint32_t d, float *delta_out) {
+  return vi::guarded([&]() -> vi_status {
   return vi::kmeans_centroid_delta(device, C_new_dev, C_prev_dev, k, d, delta_out);
+  });
 }
 
 vi_rng *vi_rng_seed_from_u64(uint64_t seed) { return reinterpret_cast<vi_rng *>(new (std::nothrow) vi::StdRng(seed)); }
@@ -291,14 +332,17 @@ vi_status vi_shard_save_to(const char *shards_dir, uint64_t shard_id, uint32_t d
                            const uint64_t *centroid_ids, const float *centroid_vecs, const uint64_t *list_off,
                            const uint64_t *ids, const uint64_t *ext_ids, const uint64_t *timestamps,
                            const float *vecs) {
+  return vi::guarded([&]() -> vi_status {
   if (!shards_dir || !list_off) return fail(VI_ERR_INVALID_INPUT, "null pointer");
   return vi::shard_save_to(shards_dir, shard_id, dim, num_lists, centroid_ids, centroid_vecs, list_off, ids, ext_ids,
                            timestamps, vecs);
+  });
 }
 
 vi_status vi_shard_get_centroid_vectors_from(const char *shards_dir, uint64_t shard_id, const uint64_t *centroid_ids,
                                              uint64_t n_req, uint32_t *dim_out, uint64_t *counts, float *centroid_out,
                                              uint64_t *metas_out, float *vecs_out) {
+  return vi::guarded([&]() -> vi_status {
   if (!shards_dir) return fail(VI_ERR_INVALID_INPUT, "null pointer");
   vi::ShardFile f;
   VI_TRY(f.open(shards_dir, shard_id));
@@ -319,6 +363,7 @@ vi_status vi_shard_get_centroid_vectors_from(const char *shards_dir, uint64_t sh
     vbase += lv->num_vectors;
   }
   return VI_OK;
+  });
 }
 
 void vi_config_init(vi_config *cfg, uint32_t dimension) {
@@ -331,6 +376,7 @@ void vi_config_init(vi_config *cfg, uint32_t dimension) {
 }
 
 vi_status vi_indexer_new(const vi_config *cfg, vi_indexer **out) {
+  return vi::guarded([&]() -> vi_status {
   if (!cfg || !out) return fail(VI_ERR_INVALID_INPUT, "null pointer");
   auto *h = new vi_indexer();
   h->impl.cfg = *cfg;
@@ -341,9 +387,11 @@ vi_status vi_indexer_new(const vi_config *cfg, vi_indexer **out) {
   h->impl.meta.dimension = cfg->dimension;
   *out = h;
   return VI_OK;
+  });
 }
 
 vi_status vi_indexer_load(const vi_config *cfg, vi_indexer **out) {
+  return vi::guarded([&]() -> vi_status {
   vi_indexer *h = nullptr;
   VI_TRY(vi_indexer_new(cfg, &h));
   vi_status st = vi::index_meta_load(h->impl.index_dir, &h->impl.meta);
@@ -351,10 +399,12 @@ vi_status vi_indexer_load(const vi_config *cfg, vi_indexer **out) {
   if (st != VI_OK) { delete h; return st; }
   *out = h;
   return VI_OK;
+  });
 }
 
 vi_status vi_indexer_build_from_records(vi_indexer *ix, const uint64_t *ext_ids, const float *values,
                                         const uint64_t *timestamps, const uint32_t *dims, uint64_t n) {
+  return vi::guarded([&]() -> vi_status {
   if (!ix) return fail(VI_ERR_INVALID_INPUT, "null indexer");
   if (n == 0) return fail(VI_ERR_INVALID_INPUT, "no vectors provided");  // api.rs:116-118
   const uint32_t dim = ix->impl.cfg.dimension;
@@ -365,9 +415,11 @@ vi_status vi_indexer_build_from_records(vi_indexer *ix, const uint64_t *ext_ids,
                     (unsigned long long)i, dim, dims[i]);
   if (!values) return fail(VI_ERR_INVALID_INPUT, "null values");
   return vi::fit_and_save(&ix->impl, values, ext_ids, timestamps, n);
+  });
 }
 
 vi_status vi_indexer_build_from_vector_file(vi_indexer *ix, const char *vector_file) {
+  return vi::guarded([&]() -> vi_status {
   if (!ix || !vector_file) return fail(VI_ERR_INVALID_INPUT, "invalid vector_file path");
   std::vector<vi::VectorFileRecord> recs;
   if (vi::read_vectors_from_file(vector_file, &recs) != VI_OK)
@@ -386,6 +438,7 @@ vi_status vi_indexer_build_from_vector_file(vi_indexer *ix, const char *vector_f
     ts[i] = recs[i].meta;  // VectorStore::new(vectors): third field is the timestamp (api.rs:181)
   }
   return vi::fit_and_save(&ix->impl, X.data(), eid.data(), ts.data(), recs.size());
+  });
 }
 
 static vi_status search_common(const vi_indexer *ix, uint64_t *k, uint64_t *n_probe) {
@@ -398,6 +451,7 @@ static vi_status search_common(const vi_indexer *ix, uint64_t *k, uint64_t *n_pr
 
 vi_status vi_indexer_search(const vi_indexer *ix, const float *queries, uint64_t nq, uint32_t query_dim, uint64_t k,
                             uint64_t n_probe, float *D, int64_t *I, float *V, uint64_t *counts, uint64_t *k_out) {
+  return vi::guarded([&]() -> vi_status {
   VI_TRY(search_common(ix, &k, &n_probe));
   if (k_out) *k_out = k;
   if (query_dim != ix->impl.cfg.dimension)  // api.rs:192-201
@@ -416,10 +470,12 @@ vi_status vi_indexer_search(const vi_indexer *ix, const float *queries, uint64_t
   io.queries = queries; io.nq = nq; io.k = k; io.n_probe = n_probe;
   io.D = D; io.I = I; io.V = V; io.counts = counts;
   return vi::device_index_search(*ix->impl.dev, io);
+  });
 }
 
 vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t k,
                                    uint64_t n_probe, float *D_dev, int64_t *I_dev, uint64_t *tie_dev) {
+  return vi::guarded([&]() -> vi_status {
   VI_TRY(search_common(ix, &k, &n_probe));
   if (k == 0 || n_probe == 0) return fail(VI_ERR_INVALID_INPUT, "k and n_probe must be greater than 0");
   if (nq == 0) return VI_OK;
@@ -429,10 +485,12 @@ vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_de
   io.queries = queries_dev; io.on_device = true; io.nq = nq; io.k = k; io.n_probe = n_probe;
   io.D = D_dev; io.I = I_dev; io.tie = tie_dev;
   return vi::device_index_search(*ix->impl.dev, io);
+  });
 }
 
 vi_status vi_indexer_probe_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t n_probe,
                                   uint32_t *probes_dev, uint32_t *order_dev, uint64_t *n_probe_eff) {
+  return vi::guarded([&]() -> vi_status {
   uint64_t k = 1;
   VI_TRY(search_common(ix, &k, &n_probe));
   if (n_probe == 0) return fail(VI_ERR_INVALID_INPUT, "k and n_probe must be greater than 0");
@@ -445,12 +503,14 @@ vi_status vi_indexer_probe_device(const vi_indexer *ix, const float *queries_dev
   io.queries = queries_dev; io.on_device = true; io.nq = nq; io.k = 1; io.n_probe = n_probe;
   io.probes_out = probes_dev; io.order_out = order_dev;
   return vi::device_index_search(*ix->impl.dev, io);
+  });
 }
 
 vi_status vi_indexer_search_probed_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t k,
                                           uint64_t n_probe_eff, const uint32_t *probes_dev,
                                           const uint32_t *order_dev, float *D_dev, int64_t *I_dev,
                                           uint64_t *tie_dev) {
+  return vi::guarded([&]() -> vi_status {
   uint64_t n_probe = n_probe_eff;
   VI_TRY(search_common(ix, &k, &n_probe));
   if (k == 0 || n_probe == 0) return fail(VI_ERR_INVALID_INPUT, "k and n_probe must be greater than 0");
@@ -464,16 +524,21 @@ vi_status vi_indexer_search_probed_device(const vi_indexer *ix, const float *que
   io.D = D_dev; io.I = I_dev; io.tie = tie_dev;
   io.probes_in = probes_dev; io.order_in = order_dev;
   return vi::device_index_search(*ix->impl.dev, io);
+  });
 }
 
 vi_status vi_merge_partials_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts, const float *D_parts,
                                    const int64_t *I_parts, const uint64_t *tie_parts, float *D_out, int64_t *I_out) {
+  return vi::guarded([&]() -> vi_status {
   return vi::merge_partials_device(device, nq, k, parts, D_parts, I_parts, tie_parts, D_out, I_out);
+  });
 }
 
 vi_status vi_merge_partials_packed_device(int32_t device, uint64_t nq, uint64_t k, uint32_t parts, const void *packed_dev,
                                           float *D_out, int64_t *I_out) {
+  return vi::guarded([&]() -> vi_status {
   return vi::merge_partials_packed_device(device, nq, k, parts, packed_dev, D_out, I_out);
+  });
 }
 
 uint64_t vi_packed_result_bytes(uint64_t nq, uint64_t k) { return (nq * k * 4 + 7) / 8 * 8 + 2 * nq * k * 8; }
@@ -484,26 +549,32 @@ uint64_t vi_indexer_num_vectors(const vi_indexer *ix) { return ix && ix->impl.de
 uint64_t vi_indexer_num_shards(const vi_indexer *ix) { return ix && ix->impl.dev ? ix->impl.dev->nshards : 0; }
 
 vi_status vi_indexer_centroids(const vi_indexer *ix, float *centroids_out, uint64_t *c2s_out) {
+  return vi::guarded([&]() -> vi_status {
   if (!ix) return fail(VI_ERR_INVALID_INPUT, "null indexer");
   const vi::IndexMeta &m = ix->impl.meta;
   if (centroids_out && !m.centroids.empty()) std::memcpy(centroids_out, m.centroids.data(), m.centroids.size() * 4);
   if (c2s_out && !m.c2s.empty()) std::memcpy(c2s_out, m.c2s.data(), m.c2s.size() * 8);
   return VI_OK;
+  });
 }
 
 void vi_indexer_free(vi_indexer *ix) { delete ix; }
 
 vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out) {
+  return vi::guarded([&]() -> vi_status {
   if (!ix || !out || !ix->impl.dev) return fail(VI_ERR_INVALID_INPUT, "no stats");
   std::lock_guard<std::mutex> lock(ix->impl.dev->mu);
   *out = ix->impl.dev->stats;
   return VI_OK;
+  });
 }
 
 vi_status vi_indexer_last_build_stats(const vi_indexer *ix, vi_build_stats *out) {
+  return vi::guarded([&]() -> vi_status {
   if (!ix || !out) return fail(VI_ERR_INVALID_INPUT, "no stats");
   *out = ix->impl.build_stats;
   return VI_OK;
+  });
 }
 
 void vi_indexer_enable_timing(vi_indexer *ix, int enable) {

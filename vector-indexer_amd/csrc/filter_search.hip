@@ -224,6 +224,7 @@ struct FilterArgs {
   float4 *gval;                // group records: the four smallest sub-block minima of a (pair, segment, lane half)
   uint32_t *gmeta;             // ... and where the record belongs: probe rank | segment << 6 | lane half << 13
   float4 *brec;                // pair records: the sub-block minima of two blocks
+  uint32_t direct;  // coarse table only: records = the minima of the 8-row sub-blocks of every block, no group records
   uint32_t xmode;  // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no ranking epilogue
 };
 
@@ -246,6 +247,10 @@ __device__ __forceinline__ float tile_min(const f32x16 &a) {
   const float m2 = min3_raw(a[6], a[7], a[8]), m3 = min3_raw(a[9], a[10], a[11]);
   const float m4 = min3_raw(a[12], a[13], a[14]);
   return min3_raw(min3_raw(m0, m1, m2), min3_raw(m3, m4, a[15]), m0);
+}
+// the minimum of registers r0 .. r0+7 of an accumulator tile: an 8-row sub-block (4 instructions)
+__device__ __forceinline__ float tile_min8(const f32x16 &a, int r0) {
+  return min3_raw(min3_raw(a[r0], a[r0 + 1], a[r0 + 2]), min3_raw(a[r0 + 3], a[r0 + 4], a[r0 + 5]), min3_raw(a[r0 + 6], a[r0 + 7], a[r0 + 6]));
 }
 // v into the sorted four smallest T0 <= T1 <= T2 <= T3 (v_med3_f32 takes its operands as they are)
 #define VI_TOP4(v)                             \
@@ -459,7 +464,14 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
           }
         }
       }
-      if (!(a.xmode & 2u)) {
+      if (TABLE && a.direct) {
+        // the coarse table (<= 256 blocks): every block's four 8-row sub-block minima go out as they are, one record per
+        // block; the select reads all of a query's records at once (coarse_select_direct_kernel)
+        stored = qlive;
+        if (qlive)
+          a.brec[((size_t)chunk * nblk + blk) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp] =
+              make_float4(tile_min8(acc0, 0), tile_min8(acc0, 8), tile_min8(acc1, 0), tile_min8(acc1, 8));
+      } else if (!(a.xmode & 2u)) {
         // all that is kept of the two 16-row sub-blocks: their minima
         const float m0 = tile_min(acc0), m1 = tile_min(acc1);
         VI_TOP4(m0) VI_TOP4(m1)
@@ -490,7 +502,7 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
       __builtin_amdgcn_s_barrier();  // next tile visible; this tile free to be overwritten
     }
   }
-  if (qlive) {
+  if (qlive && !(TABLE && a.direct)) {
     const size_t gi = (a.qoff ? (size_t)a.qoff[qid] + a.rel[slot] : (size_t)slot * a.rec_stride) + 2u * seg + (uint32_t)h;
     a.gval[gi] = make_float4(T0, T1, T2, T3);
     a.gmeta[gi] = (slot - qid * a.P) | (seg << 6) | ((uint32_t)h << 13);  // where the record belongs
@@ -935,6 +947,127 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   if (lane == 63) a.qtot[q] = ig;
 }
 
+// The coarse table up to 256 blocks (16 384 centroids): the rank kernel leaves one record per (block, lane half) — the
+// minima of its four 8-row sub-blocks — and this kernel reads ALL of a query's records at once (<= 8 per lane): the P-th
+// smallest minimum bounds the P-th distance (the minima belong to different centroids), every sub-block whose minimum is
+// at or below the threshold (*) is re-evaluated exactly, 8 rows x 8 sub-blocks per wave instruction.  No group records,
+// no refinement rounds: at P = 32 of 4096 the candidates are 1 in 13 sub-blocks.
+constexpr uint32_t kDirectBlocks = 256;
+__global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectArgs a) {
+  __shared__ uint32_t s_pick[4][kPickCap];
+  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const uint32_t q = blockIdx.x * 4 + wave;
+  if (q >= a.nq) return;
+  const SelectCommon &c = a.c;
+  uint32_t *pick = s_pick[wave];
+  float *qlds = s_q[wave];
+  const uint64_t below = (1ull << lane) - 1ull;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  float qn = 0.0f;
+  for (uint32_t e = lane; e < c.dim; e += kWave) {
+    const float v = c.Q[(size_t)q * c.dim + e];
+    qlds[e] = v;
+    qn += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  lds_sync();
+  const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  const bool distrust = !(qn < 1.0e30f);  // see select_body
+  const uint32_t K = a.P, nblk = (a.nlists + kWave - 1) / kWave, nrec = 2u * nblk;
+  const size_t base = (size_t)(q / c.gq) * nblk * (2u * c.gq) + (q % c.gq);
+  float4 R[kDirectBlocks * 2 / kWave];
+#pragma unroll
+  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i) {
+    const uint32_t rec = i * kWave + lane;  // record (block rec >> 1, lane half rec & 1)
+    R[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (rec < nrec) R[i] = c.brec[base + (size_t)(rec >> 1) * (2u * c.gq) + c.gq * (rec & 1u)];
+  }
+  WaveTopK s1;
+  s1.init();
+#pragma unroll
+  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i)
+    if (i * kWave < nrec) {
+      const bool live = i * kWave + lane < nrec;
+      s1 = offer_bulk_fn(s1, R[i].x, live ? 0u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, R[i].y, live ? 1u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, R[i].z, live ? 2u : kNoPos, (int)K);
+      s1 = offer_bulk_fn(s1, R[i].w, live ? 3u : kNoPos, (int)K);
+    }
+  float thr = INFINITY;
+  {
+    const float mk = readlane_f(s1.d, (int)K - 1);
+    if (!distrust && mk < 1.0e37f) {
+      const float scale = fmaxf(mk + qn, 0.0f) + E;
+      thr = mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
+    }
+  }
+  WaveTopK sel;
+  sel.init();
+  uint32_t npick = 0;
+  // requests: (block << 3) | (tile << 2) | (lane half << 1) | 8-row half of the 16-row sub-block; 8 per round
+  auto drain = [&]() {
+    while (npick > 0) {
+      const uint32_t cnt = npick >= 8u ? 8u : npick;
+      npick -= cnt;
+      const uint32_t rq = (uint32_t)lane >> 3;
+      bool live = rq < cnt;
+      const uint32_t ck = live ? pick[npick + rq] : 0u;
+      const uint32_t pos = (ck >> 3) * kWave + subblock_vector(8u * (ck & 1u) + ((uint32_t)lane & 7u), (ck >> 2) & 1u, (ck >> 1) & 1u,
+                                                              c.image_order != 0u);
+      live = live && pos < a.nlists && !(c.xmode & 1u);
+      sel = exact_batch_fn(sel, qlds, c.blocks + ((size_t)((live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave), c.dim, live,
+                           pos, (int)K);
+    }
+  };
+#pragma unroll
+  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i)
+    if (i * kWave < nrec) {
+      const uint32_t rec = i * kWave + lane;
+      const float bv[4] = {R[i].x, R[i].y, R[i].z, R[i].w};
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const bool want = rec < nrec && !(bv[j] > thr);
+        const uint64_t m = __ballot(want);
+        if (m) {
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          if (npick + cnt > kPickCap) drain();
+          if (want) pick[npick + (uint32_t)__popcll(m & below)] = ((rec >> 1) << 3) | ((j >> 1) << 2) | ((rec & 1u) << 1) | (j & 1u);
+          npick += cnt;
+          lds_sync();
+        }
+      }
+    }
+  drain();
+  // ---- the same tail as coarse_select_kernel: probes, candidate order, histogram, record offsets of the list phase ----
+  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
+  const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
+  const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
+  if ((uint32_t)lane < a.P) {
+    a.probes[(size_t)q * a.P + lane] = mylist;
+    a.gorder[(size_t)q * a.P + lane] = g;
+    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+  }
+  uint32_t ng = 0;
+  if (mylist != kNoPos) {
+    uint32_t sb;
+    ng = 2u * list_segments(a.list_len[mylist], a.list_segb0, &sb);
+  }
+  uint32_t ig = ng;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = (uint32_t)__shfl_up((int)ig, o);
+    if (lane >= o) ig += x;
+  }
+  if ((uint32_t)lane < a.P) a.rel[(size_t)q * a.P + lane] = ig - ng;
+  if (lane == 63) a.qtot[q] = ig;
+}
+
 template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, uint32_t gq, hipStream_t st) {
   if (nitems == 0) return VI_OK;
@@ -1128,7 +1261,9 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.c_pairs.reserve(nq));
   VI_TRY(ws.gval.reserve(nq * recs * 4));
   VI_TRY(ws.gpos.reserve(nq * recs));
-  VI_TRY(ws.brec.reserve((uint64_t)ngroups * nseg * seg_records(segb) * 256 * 4));
+  const char *de = getenv("VI_COARSE_DIRECT");
+  const bool direct = ix.centroids.nblocks <= kDirectBlocks && !(de && *de == '0');
+  VI_TRY(ws.brec.reserve((uint64_t)ngroups * (direct ? ix.centroids.nblocks : (uint64_t)nseg * seg_records(segb)) * 256 * 4));
   VI_TRY(ws.stats.reserve(16));
   if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
     VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
@@ -1147,6 +1282,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
+    a.direct = direct ? 1u : 0u;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
@@ -1155,7 +1291,8 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
                        ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
-    hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    if (direct) hipLaunchKernelGGL(coarse_select_direct_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
   return VI_OK;
