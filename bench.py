@@ -274,7 +274,7 @@ def main():
         po, pog, pa, oa = bufs_for(p_eff)
         if q1 > q0:
             index.probe_device(xq[q0:].data_ptr(), q1 - q0, n_probe, po[0].data_ptr(), po[1].data_ptr())
-        dist.all_gather_into_tensor(pog, po)
+        dist.all_gather_into_tensor(pog.view(-1), po.view(-1))  # (flat: the form both RCCL and gloo accept)
         pa.view(world, per, p_eff).copy_(pog[:, 0])
         oa.view(world, per, p_eff).copy_(pog[:, 1])
         base = mine.data_ptr()

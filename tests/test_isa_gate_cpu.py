@@ -76,9 +76,12 @@ def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
     for name, k in dbl.items():
         loop = block_loop(k["body"])
         stores = re.findall(r"^\s*global_store_\w+", loop, re.M)
-        assert stores == ["\tglobal_store_dwordx4"], f"{name}: stores in the block loop: {stores}"
+        # one pair-record store per block; the coarse-table instantiations also hold the two stores of the direct records
+        # (the two paths are exclusive and waited for with vmcnt(1) / vmcnt(2))
+        want = 3 if k["table"] else 1
+        assert stores == ["\tglobal_store_dwordx4"] * want, f"{name}: stores in the block loop: {stores}"
         loads = re.findall(r"^\s*global_load_(?!lds)\w+", loop, re.M)
         assert not loads, f"{name}: plain global loads inside the block loop: {loads}"
         assert re.search(r"global_load_lds_dwordx4", loop), name
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
-        assert "1" in waits and set(waits) <= {"0", "1"}, f"{name}: vmcnt waits {waits}"
+        assert "1" in waits and set(waits) <= ({"0", "1", "2"} if k["table"] else {"0", "1"}), f"{name}: vmcnt waits {waits}"

@@ -67,6 +67,8 @@ struct SearchWorkspace {
   DevBuf<float> gval;                       // group records: 4 smallest sub-block minima per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and where each record belongs (probe rank | segment | lane half)
   DevBuf<float> brec;                       // pair records: the 4 sub-block minima of two blocks per (record tile, lane half, query of the group)
+  struct GqHint { uint64_t nq; uint32_t P, gq; };
+  std::vector<GqHint> gq_hint;              // queries per rank work item measured to suit a batch shape (filter_search.hip)
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

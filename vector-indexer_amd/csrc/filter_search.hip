@@ -56,7 +56,7 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
 vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
                        bool histogram, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[6], hipStream_t st, bool histogram_done);
+                          uint64_t hstats[13], hipStream_t st, bool histogram_done);
 
 namespace {
 
@@ -248,9 +248,17 @@ __device__ __forceinline__ float tile_min(const f32x16 &a) {
   const float m4 = min3_raw(a[12], a[13], a[14]);
   return min3_raw(min3_raw(m0, m1, m2), min3_raw(m3, m4, a[15]), m0);
 }
-// the minimum of registers r0 .. r0+7 of an accumulator tile: an 8-row sub-block (4 instructions)
-__device__ __forceinline__ float tile_min8(const f32x16 &a, int r0) {
-  return min3_raw(min3_raw(a[r0], a[r0 + 1], a[r0 + 2]), min3_raw(a[r0 + 3], a[r0 + 4], a[r0 + 5]), min3_raw(a[r0 + 6], a[r0 + 7], a[r0 + 6]));
+// registers r0 .. r0+7 of an accumulator tile (an 8-row sub-block): the smallest value with its row in the 3 low
+// mantissa bits (|packed - m| < 2^-20 |m|) and the second smallest — 3 instructions per element
+__device__ __forceinline__ float2 tile_min8_idx(const f32x16 &a, int r0) {
+  float b1 = INFINITY, b2 = INFINITY;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float p = __uint_as_float((__float_as_uint(a[r0 + e]) & ~7u) | (uint32_t)e);
+    b2 = __builtin_amdgcn_fmed3f(b1, b2, p);
+    b1 = min3_raw(b1, p, p);
+  }
+  return make_float2(b1, b2);
 }
 // v into the sorted four smallest T0 <= T1 <= T2 <= T3 (v_med3_f32 takes its operands as they are)
 #define VI_TOP4(v)                             \
@@ -377,7 +385,7 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   __syncthreads();                     // ... and so have everyone else's
   for (uint32_t blk = b0; blk < b1; ++blk) {
     const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
-    bool stored = false;  // this lane stored a pair record in this iteration
+    uint32_t nstores = 0;  // record stores this lane issued in this iteration
     const float *s_tile = s_tiles[NBUF == 2 ? ((blk - b0) & 1u) : 0];
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
     // barrier that ended the previous iteration)
@@ -465,12 +473,17 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
         }
       }
       if (TABLE && a.direct) {
-        // the coarse table (<= 256 blocks): every block's four 8-row sub-block minima go out as they are, one record per
-        // block; the select reads all of a query's records at once (coarse_select_direct_kernel)
-        stored = qlive;
-        if (qlive)
-          a.brec[((size_t)chunk * nblk + blk) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp] =
-              make_float4(tile_min8(acc0, 0), tile_min8(acc0, 8), tile_min8(acc1, 0), tile_min8(acc1, 8));
+        // the coarse table (<= 256 blocks): per block and lane the four 8-row sub-blocks' (minimum with its row, second
+        // minimum) go out as they are — two 16-byte records; the select reads all of a query's records at once
+        // (coarse_select_direct_kernel) and re-evaluates ONE row per candidate sub-block unless the second minimum
+        // can matter too
+        nstores = qlive ? 2u : 0u;
+        if (qlive) {
+          const float2 s00 = tile_min8_idx(acc0, 0), s01 = tile_min8_idx(acc0, 8), s10 = tile_min8_idx(acc1, 0), s11 = tile_min8_idx(acc1, 8);
+          float4 *dst = a.brec + ((size_t)chunk * nblk + blk) * (4u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
+          dst[0] = make_float4(s00.x, s00.y, s01.x, s01.y);
+          dst[2u * GQ] = make_float4(s10.x, s10.y, s11.x, s11.y);
+        }
       } else if (!(a.xmode & 2u)) {
         // all that is kept of the two 16-row sub-blocks: their minima
         const float m0 = tile_min(acc0), m1 = tile_min(acc1);
@@ -478,8 +491,8 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
         if (((blk - b0) & 1u) == 0u) { w.x = m0; w.y = m1; w.z = INFINITY; w.w = INFINITY; }
         else { w.z = m0; w.w = m1; }
         if (((blk - b0) & 1u) != 0u || blk + 1 == b1) {  // the pair is complete (wave-uniform)
-          stored = qlive && !(a.xmode & 8u);
-          if (stored) a.brec[(size_t)bi + (2u * GQ) * ((blk - b0) >> 1)] = w;
+          nstores = (qlive && !(a.xmode & 8u)) ? 1u : 0u;
+          if (nstores) a.brec[(size_t)bi + (2u * GQ) * ((blk - b0) >> 1)] = w;
         }
       }
     }
@@ -492,11 +505,12 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
       __syncthreads();  // next tile visible
     } else {
       // The next tile's LDS-DMA was issued before this block's MFMAs; the only younger vector-memory operation
-      // is this wave's pair-record store, if it made one (vmcnt counts loads, stores and LDS-DMA together, in issue order).
+      // are this wave's record stores of this block, if it made any (vmcnt counts loads, stores and LDS-DMA together, in issue order).
       // Waiting for all but that store keeps the store's latency off the critical path; __syncthreads() would
       // insert vmcnt(0), hence the raw barrier (LDS reads of this tile are complete: lgkmcnt(0)).
-      // (a record store is issued iff some lane of the wave stores: the ballot is the wave-uniform form of that)
-      if (__ballot(stored) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // (a store instruction is issued iff some lane of the wave stores: the ballots are the wave-uniform form of that)
+      if (__ballot(nstores == 2u) != 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (__ballot(nstores == 1u) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // next tile visible; this tile free to be overwritten
@@ -947,20 +961,22 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   if (lane == 63) a.qtot[q] = ig;
 }
 
-// The coarse table up to 256 blocks (16 384 centroids): the rank kernel leaves one record per (block, lane half) — the
-// minima of its four 8-row sub-blocks — and this kernel reads ALL of a query's records at once (<= 8 per lane): the P-th
-// smallest minimum bounds the P-th distance (the minima belong to different centroids), every sub-block whose minimum is
-// at or below the threshold (*) is re-evaluated exactly, 8 rows x 8 sub-blocks per wave instruction.  No group records,
-// no refinement rounds: at P = 32 of 4096 the candidates are 1 in 13 sub-blocks.
+// The coarse table up to 256 blocks (16 384 centroids): the rank kernel leaves two records per (block, lane half) —
+// (minimum with its row, second minimum) of its four 8-row sub-blocks — and this kernel reads ALL of a query's records at
+// once (<= 16 per lane): the P-th smallest minimum bounds the P-th distance (the minima belong to different centroids);
+// a sub-block whose minimum is at or below the threshold (*) contributes that ONE row to the exact re-evaluation, or
+// all 8 when its second minimum is at or below the threshold too.  No group records, no refinement rounds: at P = 32
+// about 40 exact distances per query decide the probe list.
 constexpr uint32_t kDirectBlocks = 256;
+constexpr uint32_t kWholeCap = 64;  // whole 8-row sub-blocks waiting for their exact distances (per wave)
 __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap];
+  __shared__ uint32_t s_pick[4][kPickCap], s_whole[4][kWholeCap];
   __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
   const SelectCommon &c = a.c;
-  uint32_t *pick = s_pick[wave];
+  uint32_t *pick = s_pick[wave], *whole = s_whole[wave];
   float *qlds = s_q[wave];
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
@@ -979,26 +995,25 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   lds_sync();
   const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
   const bool distrust = !(qn < 1.0e30f);  // see select_body
-  const uint32_t K = a.P, nblk = (a.nlists + kWave - 1) / kWave, nrec = 2u * nblk;
-  const size_t base = (size_t)(q / c.gq) * nblk * (2u * c.gq) + (q % c.gq);
-  float4 R[kDirectBlocks * 2 / kWave];
+  const uint32_t K = a.P, nblk = (a.nlists + kWave - 1) / kWave, nrec = 4u * nblk;  // records: (block, tile, lane half)
+  const size_t base = (size_t)(q / c.gq) * nblk * (4u * c.gq) + (q % c.gq);
+  constexpr uint32_t kPer = kDirectBlocks * 4 / kWave;  // records per lane
+  float4 R[kPer];  // (min of sub-block 0 with its row, its second min, the same of sub-block 1)
 #pragma unroll
-  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i) {
-    const uint32_t rec = i * kWave + lane;  // record (block rec >> 1, lane half rec & 1)
+  for (uint32_t i = 0; i < kPer; ++i) {
+    const uint32_t rec = i * kWave + lane;  // block rec >> 2, tile (rec >> 1) & 1, lane half rec & 1
     R[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    if (rec < nrec) R[i] = c.brec[base + (size_t)(rec >> 1) * (2u * c.gq) + c.gq * (rec & 1u)];
+    if (rec < nrec) R[i] = c.brec[base + (size_t)(rec >> 2) * (4u * c.gq) + (size_t)((rec >> 1) & 1u) * (2u * c.gq) + c.gq * (rec & 1u)];
   }
+  // bound of the K-th distance: every lane's smallest minimum belongs to a different centroid, so K centroids are at
+  // or below the K-th smallest of the 64 lane minima — one 64-lane sort instead of a running top-K over all the minima
+  // (K <= 64; the bound sits a few ranks above the exact K-th minimum, which costs a few more single-row evaluations)
+  float lm = INFINITY;
+#pragma unroll
+  for (uint32_t i = 0; i < kPer; ++i) lm = min3_raw(lm, R[i].x, R[i].z);
   WaveTopK s1;
   s1.init();
-#pragma unroll
-  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i)
-    if (i * kWave < nrec) {
-      const bool live = i * kWave + lane < nrec;
-      s1 = offer_bulk_fn(s1, R[i].x, live ? 0u : kNoPos, (int)K);
-      s1 = offer_bulk_fn(s1, R[i].y, live ? 1u : kNoPos, (int)K);
-      s1 = offer_bulk_fn(s1, R[i].z, live ? 2u : kNoPos, (int)K);
-      s1 = offer_bulk_fn(s1, R[i].w, live ? 3u : kNoPos, (int)K);
-    }
+  s1 = offer_bulk_fn(s1, lm, (uint32_t)lane, (int)K);
   float thr = INFINITY;
   {
     const float mk = readlane_f(s1.d, (int)K - 1);
@@ -1009,41 +1024,64 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   }
   WaveTopK sel;
   sel.init();
-  uint32_t npick = 0;
-  // requests: (block << 3) | (tile << 2) | (lane half << 1) | 8-row half of the 16-row sub-block; 8 per round
-  auto drain = [&]() {
+  uint32_t npick = 0, nwhole = 0;
+  auto exact_rows = [&](bool live, uint32_t pos) {
+    live = live && pos < a.nlists && !(c.xmode & 1u);
+    sel = exact_batch_fn(sel, qlds, c.blocks + ((size_t)((live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave), c.dim, live, pos,
+                         (int)K);
+  };
+  // sub-block s (0/1) of record rec: its first row is register 8s of tile t of lane half h
+  auto sub_row = [&](uint32_t rec, uint32_t s, uint32_t e) {
+    return (rec >> 2) * kWave + subblock_vector(8u * s + e, (rec >> 1) & 1u, rec & 1u, c.image_order != 0u);
+  };
+  auto drain_singles = [&]() {
     while (npick > 0) {
-      const uint32_t cnt = npick >= 8u ? 8u : npick;
+      const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
       npick -= cnt;
+      const bool live = (uint32_t)lane < cnt;
+      exact_rows(live, live ? pick[npick + lane] : 0u);
+    }
+  };
+  auto drain_whole = [&]() {  // 8 sub-blocks x 8 rows per round
+    while (nwhole > 0) {
+      const uint32_t cnt = nwhole >= 8u ? 8u : nwhole;
+      nwhole -= cnt;
       const uint32_t rq = (uint32_t)lane >> 3;
-      bool live = rq < cnt;
-      const uint32_t ck = live ? pick[npick + rq] : 0u;
-      const uint32_t pos = (ck >> 3) * kWave + subblock_vector(8u * (ck & 1u) + ((uint32_t)lane & 7u), (ck >> 2) & 1u, (ck >> 1) & 1u,
-                                                              c.image_order != 0u);
-      live = live && pos < a.nlists && !(c.xmode & 1u);
-      sel = exact_batch_fn(sel, qlds, c.blocks + ((size_t)((live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave), c.dim, live,
-                           pos, (int)K);
+      const bool live = rq < cnt;
+      const uint32_t ck = live ? whole[nwhole + rq] : 0u;  // (record << 1) | sub-block
+      exact_rows(live, sub_row(ck >> 1, ck & 1u, (uint32_t)lane & 7u));
     }
   };
 #pragma unroll
-  for (uint32_t i = 0; i < kDirectBlocks * 2 / kWave; ++i)
+  for (uint32_t i = 0; i < kPer; ++i)
     if (i * kWave < nrec) {
       const uint32_t rec = i * kWave + lane;
-      const float bv[4] = {R[i].x, R[i].y, R[i].z, R[i].w};
+      const float b1[2] = {R[i].x, R[i].z}, b2[2] = {R[i].y, R[i].w};
 #pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) {
-        const bool want = rec < nrec && !(bv[j] > thr);
-        const uint64_t m = __ballot(want);
+      for (uint32_t s2 = 0; s2 < 2; ++s2) {
+        const bool cand = rec < nrec && !(b1[s2] > thr);
+        const bool all8 = cand && (!(b2[s2] > thr) || distrust);
+        const bool one = cand && !all8;
+        uint64_t m = __ballot(one);
         if (m) {
           const uint32_t cnt = (uint32_t)__popcll(m);
-          if (npick + cnt > kPickCap) drain();
-          if (want) pick[npick + (uint32_t)__popcll(m & below)] = ((rec >> 1) << 3) | ((j >> 1) << 2) | ((rec & 1u) << 1) | (j & 1u);
+          if (npick + cnt > kPickCap) drain_singles();
+          if (one) pick[npick + (uint32_t)__popcll(m & below)] = sub_row(rec, s2, __float_as_uint(b1[s2]) & 7u);
           npick += cnt;
+          lds_sync();
+        }
+        m = __ballot(all8);
+        if (m) {
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          if (nwhole + cnt > kWholeCap) drain_whole();
+          if (all8) whole[nwhole + (uint32_t)__popcll(m & below)] = (rec << 1) | s2;
+          nwhole += cnt;
           lds_sync();
         }
       }
     }
-  drain();
+  drain_whole();
+  drain_singles();
   // ---- the same tail as coarse_select_kernel: probes, candidate order, histogram, record offsets of the list phase ----
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
@@ -1263,7 +1301,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   VI_TRY(ws.gpos.reserve(nq * recs));
   const char *de = getenv("VI_COARSE_DIRECT");
   const bool direct = ix.centroids.nblocks <= kDirectBlocks && !(de && *de == '0');
-  VI_TRY(ws.brec.reserve((uint64_t)ngroups * (direct ? ix.centroids.nblocks : (uint64_t)nseg * seg_records(segb)) * 256 * 4));
+  VI_TRY(ws.brec.reserve((uint64_t)ngroups * (direct ? 2 * ix.centroids.nblocks : (uint64_t)nseg * seg_records(segb)) * 256 * 4));
   VI_TRY(ws.stats.reserve(16));
   if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
     VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
@@ -1291,6 +1329,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
                        ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
+    if (direct) a.c.e_scale += (float)(1.01 * std::ldexp(1.0, -20));  // the row index rides in 3 mantissa bits of the minima
     if (direct) hipLaunchKernelGGL(coarse_select_direct_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(coarse_select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
@@ -1356,13 +1395,31 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   }
   if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
   // ---- 2. group all (query, probe) pairs by list ----
-  uint64_t hstats[6];
+  uint64_t hstats[13];
   // queries per rank work item: 128 when lists are shared by many queries of the batch, 32 when a list is probed by a
   // handful (large balanced indexes): a 128-query group would keep three of its four waves idle
+  // The choice needs the batch's histogram, which only the grouping produces: the first batch of a shape (nq, P) goes by
+  // the mean (queries per list), every later one by what the previous batch of that shape measured — the fill a
+  // 128-query grouping has (pairs per tile slot; the grouping counts its tiles whichever size runs).  The mean alone is
+  // wrong on skewed indexes: the reference's k-means on unclustered data leaves a few enormous lists that every query
+  // probes (C5-shaped run: 4.9 queries per list on average, yet 128-query groups are three quarters full).
   const char *gqe = getenv("VI_FILTER_GQ");
-  const uint32_t gq = gqe ? (atoi(gqe) == 32 ? 32u : 128u)
-                          : ((double)nq * P / (double)std::max<uint64_t>(1, nlists) >= 24.0 ? 128u : 32u);
+  uint32_t gq = (double)nq * P / (double)std::max<uint64_t>(1, nlists) >= 24.0 ? 128u : 32u;
+  for (const auto &h : ws.gq_hint)
+    if (h.nq == nq && h.P == P) gq = h.gq;
+  if (gqe) gq = atoi(gqe) == 32 ? 32u : 128u;
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
+  {
+    const double fill128 = hstats[12] ? (double)hstats[0] / ((double)hstats[12] * 128.0 * 64.0) : 0.0;
+    const uint32_t next = fill128 >= 0.3 ? 128u : 32u;
+    bool seen = false;
+    for (auto &h : ws.gq_hint)
+      if (h.nq == nq && h.P == P) { h.gq = next; seen = true; }
+    if (!seen) {
+      if (ws.gq_hint.size() >= 64) ws.gq_hint.clear();
+      ws.gq_hint.push_back({nq, P, next});
+    }
+  }
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];

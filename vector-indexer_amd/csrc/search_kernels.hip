@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
   const uint4 *cnt4 = reinterpret_cast<const uint4 *>(cnt);  // kSubBins == 8: two uint4 per list
   uint32_t seg = 0, item = 0, run = 0, tile = 0;
-  unsigned long long vec = 0, rec = 0, mtile = 0;
+  unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
   for (uint32_t l = beg; l < end; ++l) {
     const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
     const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     run += ns > 1 ? c * ns : 0u;
     vec += (unsigned long long)c * len;
     mtile += (unsigned long long)chunks * ((len + 63) / 64);  // (query group, block) tiles ranked on the matrix cores
+    mtile128 += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);  // ... if the groups held 128 queries
     tile += chunks * ns * ((segb + 1) / 2);  // record tiles: one per (query group, 2 blocks of a segment); count checked on the host
     rec += 2ull * c * ns;
   }
@@ -417,12 +418,14 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     vec += __shfl_xor(vec, o);
     rec += __shfl_xor(rec, o);
     mtile += __shfl_xor(mtile, o);
+    mtile128 += __shfl_xor(mtile128, o);
   }
   if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
   if (lane == 0) {
     atomicAdd((unsigned long long *)&stats[0], vec);  // scanned vectors
     atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
     atomicAdd((unsigned long long *)&stats[3], mtile);
+    atomicAdd((unsigned long long *)&stats[12], mtile128);
   }
   __syncthreads();
   uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
@@ -1127,7 +1130,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.pairs.reserve(nq * P));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
-  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6], [7] belong to the MFMA path's select
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
                      ws.cnt.p + nlists * kSubBins, ws.stats.p, (uint32_t *)nullptr);
@@ -1304,7 +1307,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 // Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[6], hipStream_t st, bool histogram_done) {
+                          uint64_t hstats[13], hipStream_t st, bool histogram_done) {
   SearchWorkspace &ws = ix.ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1316,7 +1319,8 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pair_pos.reserve(total));
   VI_TRY(ws.tile_start.reserve(nlists + 1));
   VI_TRY(ws.stats.reserve(16));
-  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6], [7] belong to the MFMA path's select
+  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
+  VI_HIP(hipMemsetAsync(ws.stats.p + 12, 0, sizeof(uint64_t), st));
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
@@ -1327,7 +1331,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
                      ws.cnt.p + nlists * kSubBins, ws.stats.p, ws.tile_start.p);
   VI_HIP(hipGetLastError());
   // the host waits for the counts (grid size, scratch) while the scatter runs
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                      (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
