@@ -18,8 +18,9 @@
  *     hipStreamDefault, i.e. ordered after work already queued on the legacy null stream (where
  *     PyTorch-ROCm launches by default); callers using other streams must synchronise first.
  *     Every entry point returns only after its device work has completed.
- *   - a vi_indexer handle may be shared by several host threads (search is serialised
- *     internally per handle; the reference's search is &self, ivf_index_tests.rs:768-807)
+ *   - a vi_indexer handle may be shared by several host threads: up to 4 searches run concurrently on one handle (each
+ *     call holds its own stream and workspace; further callers wait), as the reference's &self search does
+ *     (ivf_index_tests.rs:768-807)
  */
 #ifndef VI_AMD_H
 #define VI_AMD_H

@@ -221,3 +221,30 @@ def test_build_reports_its_phases(tmp_path):
     assert st["shard_bytes"] == 20000 * (24 + 24 * 4)
     parts = sum(st[k] for k in ("ms_upload", "ms_kmeans", "ms_group", "ms_super", "ms_export", "ms_index"))
     assert st["ms_total"] > 0 and abs(parts - st["ms_total"]) < 0.05 * st["ms_total"] + 1.0
+
+
+def test_concurrent_batches_of_different_shapes_on_one_handle(tmp_path):
+    """8 threads (more than the 4 search contexts of a handle) issue batches of different sizes, k and n_probe — MFMA
+    engine, coarse step on the matrix cores, generic path — at the same time; every result equals the one the same call
+    returns alone.  (The reference's search is &self: ivf_index_tests.rs:768-807.)"""
+    rng = np.random.default_rng(17)
+    X = rng.integers(0, 60, size=(30000, 32)).astype(np.float32)
+    idx = vip.build(X, str(tmp_path), nlist=1100)
+    shapes = [(1, 10, 8), (300, 5, 16), (700, 10, 32), (64, 64, 3), (513, 1, 64), (40, 100, 70), (1000, 10, 4), (257, 20, 20)]
+    Q = [np.ascontiguousarray(rng.integers(0, 60, size=(nq, 32)).astype(np.float32)) for nq, _, _ in shapes]
+    want = [idx.search_sync(Q[i], k, p) for i, (_, k, p) in enumerate(shapes)]
+    errors = []
+
+    def worker(i):
+        try:
+            _, k, p = shapes[i]
+            for _ in range(6):
+                D, I = idx.search_sync(Q[i], k, p)
+                assert (I == want[i][1]).all() and (D.view(np.uint32) == want[i][0].view(np.uint32)).all(), shapes[i]
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(shapes))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[0]
+    assert idx.last_stats()["nq"] in {s[0] for s in shapes}

@@ -564,7 +564,7 @@ vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out) {
   return vi::guarded([&]() -> vi_status {
   if (!ix || !out || !ix->impl.dev) return fail(VI_ERR_INVALID_INPUT, "no stats");
   std::lock_guard<std::mutex> lock(ix->impl.dev->mu);
-  *out = ix->impl.dev->stats;
+  *out = ix->impl.dev->last_stats;
   return VI_OK;
   });
 }

@@ -16,6 +16,8 @@
 // (24 B meta + 4·D B + pad, shards.rs:106-114) is kept only on disk.
 #pragma once
 #include <cstdint>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -57,7 +59,6 @@ struct SearchWorkspace {
   DevBuf<uint32_t> counts;      // [nq]
   DevBuf<uint64_t> stats;       // device-side counters
   DevBuf<float> V;
-  // generic (large k / n_probe) path
   // MFMA filter path (filter_search.hip)
   DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list ...
   uint64_t c_nq = 0;                        // ... for this batch size
@@ -95,11 +96,24 @@ struct DeviceIndex {
   DevBuf<float> cent_xnorm;           // same for the coarse table
   float cent_xmax2 = 0.0f;
   DevBuf<uint32_t> c_first, c_len;    // the coarse table described as one list
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  mutable std::mutex mu;              // one search at a time per handle
-  mutable SearchWorkspace ws;
-  mutable vi_search_stats stats{};
+  hipStream_t stream = nullptr;       // uploads and index construction
+  // Searches: the reference's search is &self and runs concurrently from several OS threads
+  // (tests/ivf_index_tests.rs:768-807).  A search holds one SearchContext — its own stream, events, workspace — for
+  // the duration of the call; up to kSearchContexts calls run at once on one handle, further callers wait for a free one.
+  struct SearchContext {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SearchWorkspace ws;
+    vi_search_stats stats{};
+    ~SearchContext();
+  };
+  static constexpr int kSearchContexts = 4;
+  mutable std::mutex mu;              // guards the context pool and last_stats
+  mutable std::condition_variable cv;
+  mutable std::vector<std::unique_ptr<SearchContext>> contexts;  // created on demand
+  mutable std::vector<SearchContext *> free_contexts;
+  mutable vi_search_stats last_stats{};  // of the most recent search that finished on this handle
+  SearchContext &cur() const;         // the context the calling thread holds (device_index_search acquired it)
   bool timing = false;
 
   ~DeviceIndex();

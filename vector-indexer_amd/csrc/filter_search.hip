@@ -1163,8 +1163,8 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   const double u = 1.01 * std::ldexp(1.0, -24);
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
-  c.gval = (const float4 *)ix.ws.gval.p; c.gmeta = (const uint32_t *)ix.ws.gpos.p;
-  c.brec = (const float4 *)ix.ws.brec.p;
+  c.gval = (const float4 *)ix.cur().ws.gval.p; c.gmeta = (const uint32_t *)ix.cur().ws.gpos.p;
+  c.brec = (const float4 *)ix.cur().ws.brec.p;
   c.gamma = (float)((ix.dim + 2.0) * u);
   // |ranked value - (||v||^2 - 2 q.v)| <= e_scale (||q||^2 + 2 max||v||^2):
   //   f32 MFMA : (D+2) u'  accumulation of D products + the norm
@@ -1177,7 +1177,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.image_order = rank_bf16() ? 1u : 0u;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
-  c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.ws.stats.p : nullptr;
+  c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.cur().ws.stats.p : nullptr;
   { const char *xm = getenv("VI_SELECT_XMODE"); c.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
   return c;
 }
@@ -1280,7 +1280,7 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
 // Leaves probes / gorder and the per-list histogram (ws.cnt) behind, like stage_coarse.
 vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, uint32_t list_segb0,
                               hipStream_t st) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
@@ -1358,7 +1358,7 @@ static uint32_t list_segb0() {
 
 // coarse step alone on the matrix cores (probe export for other ranks): fills ws.probes / ws.gorder
 vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   return stage_coarse_filter(ix, Qd, nq, P, list_segb0(), st);
@@ -1367,8 +1367,8 @@ vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq
 vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                  float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
                                  bool timing, const uint32_t *probes_in, const uint32_t *order_in) {
-  SearchWorkspace &ws = ix.ws;
-  vi_search_stats &stt = ix.stats;
+  SearchWorkspace &ws = ix.cur().ws;
+  vi_search_stats &stt = ix.cur().stats;
   const uint32_t dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   (void)K;
@@ -1378,7 +1378,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.qoff.reserve(nq + 1));
   VI_TRY(ws.stats.reserve(16));
   if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
-  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
     const char *cf = getenv("VI_COARSE_FILTER");
@@ -1393,7 +1393,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
     VI_HIP(hipGetLastError());
   }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[1], st));
   // ---- 2. group all (query, probe) pairs by list ----
   uint64_t hstats[13];
   // queries per rank work item: 128 when lists are shared by many queries of the batch, 32 when a list is probed by a
@@ -1428,7 +1428,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.gval.reserve(std::max<uint64_t>(1, nrec) * 4));
   VI_TRY(ws.gpos.reserve(std::max<uint64_t>(1, nrec)));
   VI_TRY(ws.brec.reserve(std::max<uint64_t>(1, nbrec) * 4));
-  if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[2], st));
   // ---- 3. rank on the matrix cores ----
   {
     FilterArgs a{};
@@ -1453,7 +1453,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     stt.group_queries = gq;
     VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_mode, gq, st));
   }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
   // ---- 4. select ----
   {
     SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2, gq), (uint32_t)nq, P, (uint32_t)k, segb0,
@@ -1463,7 +1463,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));
   if (timing && getenv("VI_FILTER_STATS")) {
     uint64_t dbg[12];
     VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));

@@ -200,11 +200,11 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
 vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
                                       float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
                                       hipStream_t st) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   if (ix.nshards > 24576) return fail(VI_ERR_OTHER, "generic path supports at most 24576 shards");
-  vi_search_stats &stt = ix.stats;
+  vi_search_stats &stt = ix.cur().stats;
 
   // ---- A. probes: dump all coarse distances, sort each row, take the first P ----
   VI_TRY(ws.probes.reserve(nq * P));

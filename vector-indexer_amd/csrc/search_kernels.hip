@@ -760,10 +760,58 @@ vi_status launch_repack_rows(const float *src, uint32_t dim, uint32_t dq, const 
 }
 
 DeviceIndex::~DeviceIndex() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+DeviceIndex::SearchContext::~SearchContext() {
   for (auto &e : ev)
     if (e) (void)hipEventDestroy(e);
   if (stream) (void)hipStreamDestroy(stream);
 }
+
+// the context held by the calling thread: set for the duration of device_index_search (a search of ANOTHER index from
+// inside a search — the hierarchical k-means assignment does that — saves and restores it)
+static thread_local DeviceIndex::SearchContext *t_ctx = nullptr;
+
+DeviceIndex::SearchContext &DeviceIndex::cur() const { return *t_ctx; }
+
+namespace {
+struct ContextLease {
+  const DeviceIndex &ix;
+  DeviceIndex::SearchContext *mine = nullptr, *prev = nullptr;
+  explicit ContextLease(const DeviceIndex &i) : ix(i) {}
+  vi_status acquire() {
+    std::unique_lock<std::mutex> lock(ix.mu);
+    for (;;) {
+      if (!ix.free_contexts.empty()) { mine = ix.free_contexts.back(); ix.free_contexts.pop_back(); break; }
+      if ((int)ix.contexts.size() < DeviceIndex::kSearchContexts) {
+        auto c = std::make_unique<DeviceIndex::SearchContext>();
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess)
+          return fail(VI_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
+        for (auto &e : c->ev)
+          if (hipEventCreate(&e) != hipSuccess) return fail(VI_ERR_DEVICE, "hipEventCreate failed");
+        mine = c.get();
+        ix.contexts.push_back(std::move(c));
+        break;
+      }
+      ix.cv.wait(lock);
+    }
+    prev = t_ctx;
+    t_ctx = mine;
+    return VI_OK;
+  }
+  ~ContextLease() {
+    if (!mine) return;
+    t_ctx = prev;
+    {
+      std::lock_guard<std::mutex> lock(ix.mu);
+      ix.last_stats = mine->stats;
+      ix.free_contexts.push_back(mine);
+    }
+    ix.cv.notify_one();
+  }
+};
+}  // namespace
 
 // ------------------------------------------------------------------------------------------
 // upload
@@ -953,8 +1001,6 @@ static vi_status init_device_index(DeviceIndex *ix, int device, uint32_t dim, ui
   ix->dq = layout_dq(dim);
   ix->nlists = nlists;
   if (!ix->stream) VI_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamDefault));
-  for (auto &e : ix->ev)
-    if (!e) VI_HIP(hipEventCreate(&e));
   return VI_OK;
 }
 
@@ -1040,7 +1086,7 @@ vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, ui
 // ------------------------------------------------------------------------------------------
 // 1+2: coarse scan over the centroid table, merge -> ws.probes / ws.gorder, histogram in ws.cnt
 vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
@@ -1074,7 +1120,7 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
 // the workspace, and the per-list histogram the grouping scan starts from
 vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
                        bool histogram, hipStream_t st) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
@@ -1105,8 +1151,8 @@ vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uin
 vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
                                bool timing, const uint32_t *probes_in, const uint32_t *order_in) {
-  SearchWorkspace &ws = ix.ws;
-  vi_search_stats &stt = ix.stats;
+  SearchWorkspace &ws = ix.cur().ws;
+  vi_search_stats &stt = ix.cur().stats;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.run_dist.reserve(nq * P * K));
@@ -1114,10 +1160,10 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   // runs of lists that are not resident here (other rank / unreadable shard) stay empty
   VI_HIP(hipMemsetAsync(ws.run_pos.p, 0xFF, nq * P * K * sizeof(uint32_t), st));
 
-  if (timing) VI_HIP(hipEventRecord(ix.ev[0], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   if (probes_in) VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, true, st));
   else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
-  if (timing) VI_HIP(hipEventRecord(ix.ev[1], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[1], st));
   // ---- 3. group (query,probe) pairs by list ----
   const double avg_q_per_list = (double)nq * P / (double)std::max<uint64_t>(1, nlists);
   int qg_l = pick_qg(dq, avg_q_per_list, ix.order);
@@ -1139,7 +1185,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   // scatter runs
   uint64_t hstats[3] = {0, 0, 0};
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, sizeof(hstats), hipMemcpyDeviceToHost, st));
-  VI_HIP(hipEventRecord(ix.ev[5], st));
+  VI_HIP(hipEventRecord(ix.cur().ev[5], st));
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
@@ -1147,13 +1193,13 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
                        ws.seg_start.p, (uint32_t *)nullptr);
     VI_HIP(hipGetLastError());
   }
-  VI_HIP(hipEventSynchronize(ix.ev[5]));
+  VI_HIP(hipEventSynchronize(ix.cur().ev[5]));
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   const uint64_t nsegruns = hstats[2];
   VI_TRY(ws.seg_run_dist.reserve(nsegruns * K));
   VI_TRY(ws.seg_run_pos.reserve(nsegruns * K));
-  if (timing) VI_HIP(hipEventRecord(ix.ev[2], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[2], st));
   // ---- 4. list scan ----
   {
     ScanArgs a{};
@@ -1173,7 +1219,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
       VI_HIP(hipGetLastError());
     }
   }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[3], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
   // ---- 5. final merge ----
   {
     FinalMergeArgs a{ws.run_dist.p, ws.run_pos.p, (uint32_t)nq, P, K, (uint32_t)k, ws.probes.p, ws.gorder.p,
@@ -1182,7 +1228,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
                        dim3(kBlockThreads), 0, st, a);
     VI_HIP(hipGetLastError());
   }
-  if (timing) VI_HIP(hipEventRecord(ix.ev[4], st));
+  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));
   return VI_OK;
 }
 
@@ -1201,10 +1247,11 @@ __global__ void stripe_tie_kernel(uint64_t *tie, uint64_t n, uint32_t rank, uint
 }
 
 vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
-  std::lock_guard<std::mutex> lock(ix.mu);
   VI_HIP(hipSetDevice(ix.device));
-  hipStream_t st = ix.stream;
-  SearchWorkspace &ws = ix.ws;
+  ContextLease lease(ix);
+  VI_TRY(lease.acquire());
+  hipStream_t st = ix.cur().stream;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nq = io.nq, k = io.k;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
@@ -1231,7 +1278,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   uint64_t *slots = nullptr;
   if (io.V) { VI_TRY(ws.slots.reserve(nq * k)); slots = ws.slots.p; }
 
-  vi_search_stats &stt = ix.stats;
+  vi_search_stats &stt = ix.cur().stats;
   stt = vi_search_stats{};
   stt.nq = nq; stt.k = k; stt.n_probe_eff = P; stt.coarse_candidates = nq * nlists;
 
@@ -1295,11 +1342,11 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   }
   VI_HIP(hipStreamSynchronize(st));
   if (timing) {
-    (void)hipEventElapsedTime(&stt.ms_coarse, ix.ev[0], ix.ev[1]);
-    (void)hipEventElapsedTime(&stt.ms_group, ix.ev[1], ix.ev[2]);
-    (void)hipEventElapsedTime(&stt.ms_scan, ix.ev[2], ix.ev[3]);
-    (void)hipEventElapsedTime(&stt.ms_merge, ix.ev[3], ix.ev[4]);
-    (void)hipEventElapsedTime(&stt.ms_total, ix.ev[0], ix.ev[4]);
+    (void)hipEventElapsedTime(&stt.ms_coarse, ix.cur().ev[0], ix.cur().ev[1]);
+    (void)hipEventElapsedTime(&stt.ms_group, ix.cur().ev[1], ix.cur().ev[2]);
+    (void)hipEventElapsedTime(&stt.ms_scan, ix.cur().ev[2], ix.cur().ev[3]);
+    (void)hipEventElapsedTime(&stt.ms_merge, ix.cur().ev[3], ix.cur().ev[4]);
+    (void)hipEventElapsedTime(&stt.ms_total, ix.cur().ev[0], ix.cur().ev[4]);
   }
   return VI_OK;
 }
@@ -1308,7 +1355,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[13], hipStream_t st, bool histogram_done) {
-  SearchWorkspace &ws = ix.ws;
+  SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
   VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
@@ -1332,11 +1379,11 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_HIP(hipGetLastError());
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  VI_HIP(hipEventRecord(ix.ev[5], st));
+  VI_HIP(hipEventRecord(ix.cur().ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                      (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
   VI_HIP(hipGetLastError());
-  VI_HIP(hipEventSynchronize(ix.ev[5]));
+  VI_HIP(hipEventSynchronize(ix.cur().ev[5]));
   return VI_OK;
 }
 
