@@ -579,14 +579,16 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
 // The select kernels are latency-sensitive code executed once per query; inlining the two heavy pieces at
 // every call site made them ~150 KB each and instruction-fetch bound.  They are real functions with their state
 // passed and returned in registers.
-__device__ __attribute__((noinline)) WaveTopK offer_bulk_fn(WaveTopK s, float dist, uint32_t pos, int K) {
+template <class Top>
+__device__ __attribute__((noinline)) Top offer_bulk_fn(Top s, float dist, uint32_t pos, int K) {
   s.offer_bulk(dist, pos, K);
   return s;
 }
 
 // exact distance of (qrow, xv) on live lanes, then offer (distance, key) to `sel`
-__device__ __attribute__((noinline)) WaveTopK exact_batch_fn(WaveTopK sel, const float *qrow, const float4 *xv,
-                                                              uint32_t dim, bool live, uint32_t key, int K) {
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_fn(Top sel, const float *qrow, const float4 *xv, uint32_t dim, bool live,
+                                                        uint32_t key, int K) {
   float d = INFINITY;
   if (live) d = exact_pair(qrow, xv, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
@@ -606,10 +608,12 @@ constexpr uint32_t kSubBits = 21;      // request key = (probe rank << 22) | (su
 constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/half) kept in LDS per wave
 
 // One wave: top-K of query q under (exact distance, (g << 26) | position) from its G group records at gbase.
-// Leaves the result in `sel` (lane i = i-th result, sel.p == kNoPos when there are fewer than K).
+// Leaves the result in `sel` (entry e of lane i = result 64e + i, key kNoPos when there are fewer than K).
+// Top = WaveTopK (K <= 64) or WaveTop128 (K <= 128: the Faiss-style harness asks for 100 neighbours).
+template <class Top>
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick, float4 *tcache,
-                                            uint32_t *lcache, float *qlds, WaveTopK &sel) {
+                                            uint32_t *lcache, float *qlds, Top &sel) {
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -634,7 +638,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     return mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
   };
   uint32_t npick = 0, n_exact = 0, n_scanned = 0, n_full = 0, n_sub = 0;
-  WaveTopK s1;
+  Top s1;
   float thr = INFINITY;
   sel.init();
   const float *qrow = qlds;  // (visible to the wave after the lds_sync of stage 0)
@@ -774,7 +778,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       s1 = offer_bulk_fn(s1, T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
       s1 = offer_bulk_fn(s1, T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
     }
-    thr = threshold_of(readlane_f(s1.d, (int)K - 1));
+    thr = threshold_of(s1.kth((int)K));
     for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
       const uint32_t gidx = gb + lane;
       const float4 T = group_values(gidx, gidx < G);
@@ -787,30 +791,14 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   //      the running top-K, then offer its pair records ----
   if (any_full && !distrust && !(c.xmode & 4u)) {
     {
-      const bool mine = s1.p != kNoPos && (uint32_t)lane < K;  // entries beyond the K-th are not needed
-      const uint32_t g = mine ? (s1.p >> 2) : 0u;
-      const bool drop = mine && group_values(g, true).w <= thr;
-      const bool keep = mine && !drop;
-      const uint64_t km = __ballot(keep);
-      // survivors close ranks: the lane of rank i fetches the i-th surviving entry
-      uint64_t rest = km;
-      int src = 63;
-      const int want = lane;
-      const int nkeep = __popcll(km);
-      // position of the want-th set bit of km (serial over <= K set bits: K <= 64)
-      int seen = 0;
-      for (int b = 0; b < nkeep; ++b) {
-        const int pos = __builtin_ctzll(rest);
-        rest &= rest - 1ull;
-        if (seen == want) src = pos;
-        ++seen;
+      bool keep[2] = {false, false};
+#pragma unroll
+      for (int e = 0; e < Top::kEntries; ++e) {
+        const uint32_t key = s1.ent_p(e);
+        const bool mine = key != kNoPos && (uint32_t)(64 * e + lane) < K;  // entries beyond the K-th are not needed
+        keep[e] = mine && !(group_values(mine ? (key >> 2) : 0u, true).w <= thr);
       }
-      const float nd = __shfl(s1.d, src);
-      const uint32_t np = (uint32_t)__shfl((int)s1.p, src);
-      s1.d = lane < nkeep ? nd : INFINITY;
-      s1.p = lane < nkeep ? np : kNoPos;
-      s1.thr = readlane_f(s1.d, (int)K - 1);
-      s1.thrp = readlane_u(s1.p, (int)K - 1);
+      s1.rebuild(keep[0], keep[1], (int)K);  // the survivors close ranks
     }
     for (uint32_t gb = 0; gb < G; gb += kWave) {
       const uint32_t gidx = gb + lane;
@@ -819,7 +807,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       group_place(gidx, live, r, seg, hh);
       scan_groups(live && group_values(gidx, live).w <= thr, r, seg, hh, 0);
     }
-    thr = fminf(thr, threshold_of(readlane_f(s1.d, (int)K - 1)));
+    thr = fminf(thr, threshold_of(s1.kth((int)K)));
   }
   // ---- stage 2: exact re-evaluation of every sub-block whose minimum is at or below thr; such a sub-block sits in a
   //      group whose smallest minimum is at or below thr ----
@@ -855,6 +843,7 @@ struct SelectArgs {
 };
 
 // one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
+template <class Top>
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
@@ -878,32 +867,37 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
       pr.boff = (a.tile_start[mylist] + (pp / a.c.gq) * nseg * seg_records(pr.segb)) * (2u * a.c.gq) + (pp % a.c.gq);
     }
   }
-  WaveTopK sel;
-  select_body(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
-              s_lcache[wave], s_q[wave], sel);
-  // lane i holds result i: map the candidate-order rank g back to the probe rank r
-  const uint32_t g = sel.p >> kPosBits, pos = sel.p & kPosMask;
-  uint32_t r = 0;
-  for (uint32_t rr = 0; rr < a.P; ++rr) {
-    const uint32_t gv = readlane_u(pr.g, (int)rr);
-    if (gv == g) r = rr;
-  }
-  const bool have = (uint32_t)lane < a.k && sel.p != kNoPos;
-  const uint32_t found = (uint32_t)__popcll(__ballot(have));
-  const uint32_t fbk = (uint32_t)__shfl((int)pr.fb, (int)r);
-  if ((uint32_t)lane < a.k) {
-    const size_t o = (size_t)q * a.k + lane;
-    if (have) {
-      const uint64_t gslot = (uint64_t)fbk * kWave + pos;
-      a.D[o] = sel.d;
-      a.I[o] = (int64_t)a.ext_ids[gslot];
-      if (a.tie) a.tie[o] = ((uint64_t)g << 32) | pos;
-      if (a.slots) a.slots[o] = gslot;
-    } else {
-      a.D[o] = INFINITY;
-      a.I[o] = -1;
-      if (a.tie) a.tie[o] = ~0ull;
-      if (a.slots) a.slots[o] = ~0ull;
+  Top sel;
+  select_body<Top>(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
+                   s_lcache[wave], s_q[wave], sel);
+  // entry e of lane i holds result 64e + i: map the candidate-order rank g back to the probe rank r
+  uint32_t found = 0;
+#pragma unroll
+  for (int e = 0; e < Top::kEntries; ++e) {
+    const uint32_t key = sel.ent_p(e), idx = 64u * (uint32_t)e + (uint32_t)lane;
+    const uint32_t g = key >> kPosBits, pos = key & kPosMask;
+    uint32_t r = 0;
+    for (uint32_t rr = 0; rr < a.P; ++rr) {
+      const uint32_t gv = readlane_u(pr.g, (int)rr);
+      if (gv == g) r = rr;
+    }
+    const bool have = idx < a.k && key != kNoPos;
+    found += (uint32_t)__popcll(__ballot(have));
+    const uint32_t fbk = (uint32_t)__shfl((int)pr.fb, (int)r);
+    if (idx < a.k) {
+      const size_t o = (size_t)q * a.k + idx;
+      if (have) {
+        const uint64_t gslot = (uint64_t)fbk * kWave + pos;
+        a.D[o] = sel.ent_d(e);
+        a.I[o] = (int64_t)a.ext_ids[gslot];
+        if (a.tie) a.tie[o] = ((uint64_t)g << 32) | pos;
+        if (a.slots) a.slots[o] = gslot;
+      } else {
+        a.D[o] = INFINITY;
+        a.I[o] = -1;
+        if (a.tie) a.tie[o] = ~0ull;
+        if (a.slots) a.slots[o] = ~0ull;
+      }
     }
   }
   if (a.counts && lane == 0) a.counts[q] = found;
@@ -934,7 +928,7 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
     pr.boff = (q / a.c.gq) * (a.recs / 2u) * seg_records(a.segb) * (2u * a.c.gq) + (q % a.c.gq);  // pairs = iota: the query's own position
   }
   WaveTopK sel;
-  select_body(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
+  select_body<WaveTopK>(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
               s_lcache[wave], s_q[wave], sel);
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
@@ -1341,7 +1335,7 @@ bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint
   const char *force = getenv("VI_FILTER");
   if (force && *force == '0') return false;
   if (ix.order != VI_ORDER_SCALAR || ix.dim > 128 || (ix.dim & 3) || ix.dim < 4) return false;
-  if (k > kMaxSelect || P > kMaxSelect || P < 1) return false;
+  if (k > 2 * kMaxSelect || P > kMaxSelect || P < 1) return false;  // k <= 128 (WaveTop128), n_probe <= 64
   if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // record position < 2^26, block < 2^20
   if (!(ix.xmax2 < 1.0e30f) || !(ix.cent_xmax2 < 1.0e30f)) return false;  // norms must stay far below kBig
   (void)nq;
@@ -1460,7 +1454,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
-    hipLaunchKernelGGL(select_kernel, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));

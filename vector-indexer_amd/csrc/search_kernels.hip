@@ -1259,7 +1259,9 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   if (nq * std::max<uint64_t>(k, 64) > 0x7FFFFFFFull) return fail(VI_ERR_INVALID_INPUT, "batch too large: split nq");
   const uint32_t P = (uint32_t)std::min<uint64_t>(io.n_probe, nlists);  // take(n_probe) (ivf_index.rs:216-220)
   const uint32_t K = (uint32_t)std::min<uint64_t>(k, kMaxSelect);
-  const bool generic = P > kMaxSelect || k > kMaxSelect || env_u32("VI_FORCE_GENERIC", 0) != 0;
+  // k in (64, 128]: the MFMA engine's select keeps two entries per lane; the VALU engine's wave top-k stops at 64
+  const bool generic = P > kMaxSelect || k > 2 * kMaxSelect || (k > kMaxSelect && !filter_path_applicable(ix, nq, k, P)) ||
+                       env_u32("VI_FORCE_GENERIC", 0) != 0;
 
   // ---- outputs / queries on device ----
   const float *Qd = io.queries;

@@ -110,6 +110,86 @@ struct WaveTopK {
     thr = readlane_f(d, K - 1);
     thrp = readlane_u(p, K - 1);
   }
+  // ---- the interface the select kernels are written against (WaveTop128 below offers the same) ----
+  static constexpr int kEntries = 1;  // entries per lane
+  __device__ __forceinline__ float kth(int K) const { return readlane_f(d, K - 1); }
+  __device__ __forceinline__ float ent_d(int) const { return d; }       // entry e of this lane = rank 64*e + lane
+  __device__ __forceinline__ uint32_t ent_p(int) const { return p; }
+  // keep only the entries flagged keep_e (of the first K): the survivors close ranks
+  __device__ __forceinline__ void rebuild(bool keep0, bool, int K) {
+    const float kd = keep0 ? d : INFINITY;
+    const uint32_t kp = keep0 ? p : kNoPos;
+    init();
+    offer_bulk(kd, kp, K);
+  }
+};
+
+// The same for K <= 128: lane i holds entries i (d0, p0) and 64 + i (d1, p1) of the ascending list.  Only the bulk
+// offer exists (the select kernels use nothing else): the 64 incoming pairs are sorted descending; their pairwise
+// minima with the upper half are the 64 smallest of (upper half, incoming) — a bitonic sequence, merged ascending;
+// that half, reversed, against the lower half gives the new lower half (minima) and upper half (maxima), both
+// bitonic again: 39 compare-exchange steps against 27 of the 64-entry form.
+struct WaveTop128 {
+  float d0, d1;
+  uint32_t p0, p1;
+  float thr;
+  uint32_t thrp;
+  static constexpr int kEntries = 2;
+  __device__ __forceinline__ void init() {
+    d0 = d1 = INFINITY; p0 = p1 = kNoPos; thr = INFINITY; thrp = kNoPos;
+  }
+  __device__ __forceinline__ float kth(int K) const { return K <= 64 ? readlane_f(d0, K - 1) : readlane_f(d1, K - 65); }
+  __device__ __forceinline__ float ent_d(int e) const { return e ? d1 : d0; }
+  __device__ __forceinline__ uint32_t ent_p(int e) const { return e ? p1 : p0; }
+  __device__ __forceinline__ void set_thr(int K) {
+    thr = K <= 64 ? readlane_f(d0, K - 1) : readlane_f(d1, K - 65);
+    thrp = K <= 64 ? readlane_u(p0, K - 1) : readlane_u(p1, K - 65);
+  }
+  __device__ __forceinline__ void offer_bulk(float dist, uint32_t pos, int K) {
+    const bool pass = (dist < thr) || (dist == thr && pos < thrp);
+    if (!__ballot(pass)) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    float v = pass ? dist : INFINITY;
+    uint32_t k = pass ? pos : kNoPos;
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {  // bitonic sort of the incoming pairs, DESCENDING
+#pragma unroll
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        const bool lower = (lane & j) == 0;
+        const bool desc_block = (lane & kk) == 0;
+        WaveTopK::cmpx(v, k, j, lower != desc_block);
+      }
+    }
+    {  // upper half (ascending) vs incoming (descending): the minima are the 64 smallest of the two
+      const bool in_less = (v < d1) || (v == d1 && k < p1);
+      d1 = in_less ? v : d1;
+      p1 = in_less ? k : p1;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) WaveTopK::cmpx(d1, p1, j, (lane & j) == 0);
+    {  // lower half (ascending) vs that half reversed (descending): minima stay below, maxima go above
+      const float rv = __shfl(d1, 63 - lane);
+      const uint32_t rk = (uint32_t)__shfl((int)p1, 63 - lane);
+      const bool r_less = (rv < d0) || (rv == d0 && rk < p0);
+      d1 = r_less ? d0 : rv;
+      p1 = r_less ? p0 : rk;
+      d0 = r_less ? rv : d0;
+      p0 = r_less ? rk : p0;
+    }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+      WaveTopK::cmpx(d0, p0, j, (lane & j) == 0);
+      WaveTopK::cmpx(d1, p1, j, (lane & j) == 0);
+    }
+    set_thr(K);
+  }
+  __device__ __forceinline__ void rebuild(bool keep0, bool keep1, int K) {
+    const float a = keep0 ? d0 : INFINITY, b = keep1 ? d1 : INFINITY;
+    const uint32_t ap = keep0 ? p0 : kNoPos, bp = keep1 ? p1 : kNoPos;
+    init();
+    offer_bulk(a, ap, K);
+    offer_bulk(b, bp, K);
+  }
 };
 
 
