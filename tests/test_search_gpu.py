@@ -476,3 +476,21 @@ def test_k_up_to_128_runs_on_the_mfma_engine(tmp_path, monkeypatch):
     orc2, gpu2 = oracle_and_gpu(tmp_path / "s", Xs, nlist=3)
     check_parity(orc2, gpu2, Q[:50], 100, 2)
     check_parity(orc2, gpu2, Q[:50], 128, 3)
+
+
+@pytest.mark.parametrize("d,n,nlist", [(256, 6000, 40), (768, 3000, 24), (1536, 2000, 16), (144, 5000, 30), (132, 3000, 20),
+                                       (1532, 1200, 9)])
+def test_wide_vectors_run_on_the_mfma_engine(d, n, nlist, tmp_path):
+    """128 < D <= 1536 (the reference tests D=1536, ivf_index_tests.rs:661-686; bench.yaml lists 256 and 768): the GEMM-shaped
+    rank kernel (C tile of 256 vectors x 128 queries, both operands through LDS) + the same select; ids and distance bits
+    of the oracle, ragged dimension counts (not a multiple of 16 or 32) included"""
+    rng = np.random.default_rng(d + n)
+    centers = rng.standard_normal((12, d)).astype(np.float32) * 3
+    X = (centers[rng.integers(0, 12, n)] + rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    Q = np.concatenate([(centers[rng.integers(0, 12, 330)] + rng.standard_normal((330, d)).astype(np.float32)).astype(np.float32), X[:30]])
+    for k, n_probe in [(10, 4), (1, 1), (64, 9), (100, 5)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+        if os.environ.get("VI_FILTER") != "0" and os.environ.get("VI_FILTER_BF16") != "0":
+            assert gpu.last_stats()["rank_mode"] == 2, (k, n_probe)
+    check_parity(orc, gpu, Q[:5], 10, 4)

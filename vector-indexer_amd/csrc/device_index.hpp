@@ -67,6 +67,7 @@ struct SearchWorkspace {
   DevBuf<uint32_t> tile_start, pair_pos;    // pair records: first record tile of each list; position of a (query, probe) pair in its list
   DevBuf<float> gval;                       // group records: 4 smallest sub-block minima per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and where each record belongs (probe rank | segment | lane half)
+  DevBuf<uint32_t> qimg;                    // wide vectors: query-major bf16 hi/lo image of the batch
   DevBuf<float> brec;                       // pair records: the 4 sub-block minima of two blocks per (record tile, lane half, query of the group)
   struct GqHint { uint64_t nq; uint32_t P, gq; };
   std::vector<GqHint> gq_hint;              // queries per rank work item measured to suit a batch shape (filter_search.hip)

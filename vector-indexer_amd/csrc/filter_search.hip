@@ -63,6 +63,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
+constexpr uint32_t kMaxFilterDim = 1536;  // the MFMA engine's dimension limit (rank_wide_kernel above 128)
 constexpr int kGroupQ = 128;       // queries per work item: 4 waves x one MFMA column tile of 32
 constexpr uint32_t kPosBits = 26;  // candidate key = (probe rank << 26) | position in list
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
@@ -524,6 +525,184 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
 }
 
 // ------------------------------------------------------------------------------------------
+// rank kernel for wide vectors (128 < D <= 1536)
+// ------------------------------------------------------------------------------------------
+// Above 128 dimensions the queries of a group no longer fit in registers for a whole work item, so the ranking becomes
+// a GEMM proper: per workgroup a C tile of 4 blocks (256 vectors) x 128 queries stays in the accumulators (128 VGPRs
+// per wave) while BOTH operands stream through LDS in K steps of 32 dimensions — 32 KB of the blocks' bf16 hi/lo image
+// and 16 KB of the queries' (gathered by LDS-DMA with per-lane row addresses from a query-major image of the batch,
+// split once per search), double buffered: 97 KB of LDS, one workgroup per CU, 24 MFMAs per wave and 16-dim chunk.
+// What a C tile leaves behind is what filter_kernel leaves: sub-block minima in pair records and the segment's four
+// smallest in a group record, so the select is the same kernel.
+constexpr int kWideBlocks = 4;
+constexpr int kWideChunks = 2;
+constexpr int kWideBufFloats = (kWideBlocks + 2) * kWideChunks * 4 * 256;  // A: 4 blocks, B: 2 query blocks; x chunks x 4 pieces x 1 KB
+constexpr int kWideLdsFloats = 2 * kWideBufFloats + kWideBlocks * 64;      // two buffers + the norms of the C tile's blocks (97 KB)
+
+struct WideArgs {
+  const uint4 *img;      // bf16 hi/lo image of the lists: per block nc chunks x [plane][half] x 64 columns x 16 B
+  const float *xnorm;    // squared norms in image-column order
+  const uint4 *qimg;     // query-major image of the batch: [query][nc][plane][half] x 16 B of -2 q split hi / lo
+  uint32_t nc;           // 16-dim chunks per vector
+  const uint32_t *first_block, *list_len, *item_start, *seg_start, *pairs, *item_list;
+  uint32_t P, segb0;
+  const uint32_t *qoff, *rel, *tile_start;
+  float4 *gval;
+  uint32_t *gmeta;
+  float4 *brec;
+};
+
+// -2 q split hi / lo, query-major: piece (chunk c, plane p, half h) of query q at (q * nc + c) * 4 + 2p + h
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (query, chunk, half)
+  if (t >= (uint64_t)nq * nc * 2) return;
+  const uint32_t h = (uint32_t)(t & 1u);
+  const uint64_t qc = t >> 1;
+  const uint32_t c = (uint32_t)(qc % nc);
+  const uint64_t q = qc / nc;
+  const uint32_t e = 16 * c + 8 * h;
+  const float *row = Q + q * dim;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (e < dim) v0 = *reinterpret_cast<const float4 *>(row + e);        // dim % 4 == 0
+  if (e + 4 < dim) v1 = *reinterpret_cast<const float4 *>(row + e + 4);
+  uint4 hi, lo;
+  split8(v0, v1, -2.0f, hi, lo);
+  out[qc * 4 + h] = hi;
+  out[qc * 4 + 2 + h] = lo;
+}
+
+__global__ void __launch_bounds__(256, 1) rank_wide_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_wide[];
+  float *s_norm = s_wide + 2 * kWideBufFloats;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t item = blockIdx.x;
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.item_list[item]);
+  const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
+  const uint32_t len = a.list_len[l];
+  uint32_t segb;
+  const uint32_t nseg = list_segments(len, a.segb0, &segb);
+  const uint32_t local = item - a.item_start[l];
+  const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
+  const uint32_t j0 = chunk * kGroupQ;
+  const uint32_t nqi = min((uint32_t)kGroupQ, cnt - j0);
+  const uint32_t fb = a.first_block[l];
+  const uint32_t nblk = (len + kWave - 1) / kWave;
+  const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
+  const uint32_t nc = a.nc, nslab = (nc + kWideChunks - 1) / kWideChunks;
+
+  // this lane's query (both lane halves hold query j of the wave's tile), and the two queries it gathers for the B tiles
+  const uint32_t wtile = ((uint32_t)wave + item) & 3u;
+  const uint32_t jq_grp = 32u * wtile + (uint32_t)j;
+  const bool qlive = jq_grp < nqi;
+  const bool wave_live = 32u * wtile < nqi;
+  const uint32_t slot = qlive ? a.pairs[s0 + j0 + jq_grp] : 0u;
+  const uint32_t qid = slot / a.P;
+  uint32_t gq[2];  // query of column `lane` of query block 0 / 1
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const uint32_t col = 64u * qb + (uint32_t)lane;
+    gq[qb] = col < nqi ? a.pairs[s0 + j0 + col] / a.P : 0u;
+  }
+
+  float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;
+  const uint32_t bi = (a.tile_start[l] + (chunk * nseg + seg) * seg_records(segb)) * (2u * kGroupQ) + (uint32_t)kGroupQ * (uint32_t)h + jq_grp;
+
+  // one K step (slab s of the C tile at blk0) into buffer `buf`: 32 A pieces + 16 B pieces of 1 KB, 12 per wave
+  auto stage = [&](uint32_t blk0, uint32_t s, float *buf) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int pi = wave + 4 * i;
+      if (pi < 32) {
+        const uint32_t blk = (uint32_t)pi >> 3, c = ((uint32_t)pi >> 2) & 1u, piece = (uint32_t)pi & 3u;
+        const uint32_t cc = s * kWideChunks + c;
+        if (blk0 + blk < b1 && cc < nc)
+          glds16_asm(a.img + (((size_t)(fb + blk0 + blk) * nc + cc) * 4 + piece) * kWave + lane, buf + pi * 256);
+      } else {
+        const uint32_t r = (uint32_t)pi - 32u, qb = r >> 3, c = (r >> 2) & 1u, piece = r & 3u;
+        const uint32_t cc = s * kWideChunks + c;
+        if (cc < nc) glds16_asm(a.qimg + ((size_t)gq[qb] * nc + cc) * 4 + piece, buf + pi * 256);
+      }
+    }
+  };
+
+  for (uint32_t blk0 = b0; blk0 < b1; blk0 += kWideBlocks) {
+    const uint32_t nb = min((uint32_t)kWideBlocks, b1 - blk0);  // blocks of this C tile
+    stage(blk0, 0, s_wide);
+    if ((uint32_t)wave < nb) glds4_asm(a.xnorm + (size_t)(fb + blk0 + wave) * kWave + lane, s_norm + wave * 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 acc[kWideBlocks][2];
+#pragma unroll
+    for (int b = 0; b < kWideBlocks; ++b)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {  // rows 8*q4 + 4*h + (0..3) of tile t live in regs 4*q4 .. 4*q4+3
+          const float4 n = *reinterpret_cast<const float4 *>(s_norm + b * 64 + 32 * t + 8 * q4 + 4 * h);
+          acc[b][t][4 * q4 + 0] = n.x; acc[b][t][4 * q4 + 1] = n.y; acc[b][t][4 * q4 + 2] = n.z; acc[b][t][4 * q4 + 3] = n.w;
+        }
+    for (uint32_t s = 0; s < nslab; ++s) {
+      const float *buf = s_wide + (s & 1u) * kWideBufFloats;
+      if (s + 1 < nslab) stage(blk0, s + 1, s_wide + ((s + 1u) & 1u) * kWideBufFloats);
+      if (wave_live) {
+        const float *bq = buf + (32 + 8 * (int)(wtile >> 1)) * 256;  // this wave's query block
+        const int qcol = 32 * (int)(wtile & 1u) + j;
+#pragma unroll
+        for (int c = 0; c < kWideChunks; ++c) {
+          if (s * kWideChunks + c < nc) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(bq + ((c * 4 + 0 + h) * 64 + qcol) * 4));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(bq + ((c * 4 + 2 + h) * 64 + qcol) * 4));
+#pragma unroll
+            for (int b = 0; b < kWideBlocks; ++b) {
+              if ((uint32_t)b < nb) {
+                const float *ab = buf + (b * 8 + c * 4) * 256;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                  const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(ab + ((0 + h) * 64 + 32 * t + j) * 4));
+                  const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(ab + ((2 + h) * 64 + 32 * t + j) * 4));
+                  acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[b][t], 0, 0, 0);
+                  acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[b][t], 0, 0, 0);
+                  acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[b][t], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+      }
+      // the next step's tiles have landed (nothing but the LDS-DMA is in flight), every wave is done with this buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (wave_live) {
+      float m[kWideBlocks][2];
+#pragma unroll
+      for (int b = 0; b < kWideBlocks; ++b) {
+        m[b][0] = INFINITY; m[b][1] = INFINITY;
+        if ((uint32_t)b < nb) {
+          m[b][0] = tile_min(acc[b][0]);
+          m[b][1] = tile_min(acc[b][1]);
+          VI_TOP4(m[b][0]) VI_TOP4(m[b][1])
+        }
+      }
+      if (qlive) {
+        const uint32_t p0 = (blk0 - b0) >> 1;
+        a.brec[(size_t)bi + (2u * kGroupQ) * p0] = make_float4(m[0][0], m[0][1], m[1][0], m[1][1]);
+        if (nb > 2) a.brec[(size_t)bi + (2u * kGroupQ) * (p0 + 1u)] = make_float4(m[2][0], m[2][1], m[3][0], m[3][1]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record stores, before the next C tile counts its DMA
+    __syncthreads();                                    // s_norm and both buffers are free again
+  }
+  if (qlive) {
+    const size_t gi = (size_t)a.qoff[qid] + a.rel[slot] + 2u * seg + (uint32_t)h;
+    a.gval[gi] = make_float4(T0, T1, T2, T3);
+    a.gmeta[gi] = (slot - qid * a.P) | (seg << 6) | ((uint32_t)h << 13);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // select
 // ------------------------------------------------------------------------------------------
 struct SelectCommon {
@@ -602,7 +781,7 @@ __device__ __forceinline__ uint32_t subblock_vector(uint32_t e, uint32_t t, uint
   return image_order ? 32u * t + 16u * hh + e : 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * hh;
 }
 
-constexpr uint32_t kMaxFilterDim = 128;  // the MFMA engine's dimension limit (filter_path_applicable)
+constexpr uint32_t kNarrowDim = 128;     // up to here the queries of a work item stay in registers (filter_kernel)
 constexpr uint32_t kPickCap = 256;     // sub-blocks waiting for their 16 exact distances (per wave)
 constexpr uint32_t kSubBits = 21;      // request key = (probe rank << 22) | (sub-block of the list << 1) | lane half
 constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/half) kept in LDS per wave
@@ -847,7 +1026,7 @@ template <class Top>
 __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
-  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
+  extern __shared__ __attribute__((aligned(16))) float s_qrows[];  // the 4 query rows of the workgroup: 4 x dim floats
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -869,7 +1048,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   }
   Top sel;
   select_body<Top>(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
-                   s_lcache[wave], s_q[wave], sel);
+                   s_lcache[wave], s_qrows + (size_t)wave * a.c.dim, sel);
   // entry e of lane i holds result 64e + i: map the candidate-order rank g back to the probe rank r
   uint32_t found = 0;
 #pragma unroll
@@ -918,7 +1097,7 @@ struct CoarseSelectArgs {
 __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
-  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
+  __shared__ __attribute__((aligned(16))) float s_q[4][kNarrowDim];  // (the coarse step runs here only for D <= 128)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -965,7 +1144,7 @@ constexpr uint32_t kDirectBlocks = 256;
 constexpr uint32_t kWholeCap = 64;  // whole 8-row sub-blocks waiting for their exact distances (per wave)
 __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_whole[4][kWholeCap];
-  __shared__ __attribute__((aligned(16))) float s_q[4][kMaxFilterDim];
+  __shared__ __attribute__((aligned(16))) float s_q[4][kNarrowDim];  // (the coarse step runs here only for D <= 128)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
@@ -1232,7 +1411,7 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
                        ix->cent_xnorm.p, cslots, ix->cent_xnorm_img.p);
   VI_HIP(hipGetLastError());
   // bf16 hi/lo images of the lists and of the centroid table (same size as the f32 blocks)
-  if ((ix->dim & 3) == 0 && ix->dim <= 128) {
+  if ((ix->dim & 3) == 0 && ix->dim <= kMaxFilterDim) {
     const uint64_t per_block = (uint64_t)ix->dq * kWave * 4;  // uint32 words per block
     VI_TRY(ix->lists_bf16.reserve(std::max<uint64_t>(1, ix->lists.nblocks * per_block)));
     VI_TRY(ix->cent_bf16.reserve(std::max<uint64_t>(1, ix->centroids.nblocks * per_block)));
@@ -1334,7 +1513,8 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
 bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint32_t P) {
   const char *force = getenv("VI_FILTER");
   if (force && *force == '0') return false;
-  if (ix.order != VI_ORDER_SCALAR || ix.dim > 128 || (ix.dim & 3) || ix.dim < 4) return false;
+  if (ix.order != VI_ORDER_SCALAR || ix.dim > kMaxFilterDim || (ix.dim & 3) || ix.dim < 4) return false;
+  if (ix.dim > kNarrowDim && !rank_bf16()) return false;  // the wide kernel ranks with bf16 x 3 only
   if (k > 2 * kMaxSelect || P > kMaxSelect || P < 1) return false;  // k <= 128 (WaveTop128), n_probe <= 64
   if (ix.lists.nblocks * 64ull >= (1ull << kPosBits)) return false;  // record position < 2^26, block < 2^20
   if (!(ix.xmax2 < 1.0e30f) || !(ix.cent_xmax2 < 1.0e30f)) return false;  // norms must stay far below kBig
@@ -1376,7 +1556,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
     const char *cf = getenv("VI_COARSE_FILTER");
-    if (!probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024) {
+    if (!probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024 && ix.dim <= kNarrowDim) {
       VI_TRY(stage_coarse_filter(ix, Qd, nq, P, segb0, st));
     } else {
       if (probes_in) VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, true, st));
@@ -1402,6 +1582,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   for (const auto &h : ws.gq_hint)
     if (h.nq == nq && h.P == P) gq = h.gq;
   if (gqe) gq = atoi(gqe) == 32 ? 32u : 128u;
+  if (ix.dim > kNarrowDim) gq = 128u;  // the wide kernel's C tile holds 128 queries
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
   {
     const double fill128 = hstats[12] ? (double)hstats[0] / ((double)hstats[12] * 128.0 * 64.0) : 0.0;
@@ -1424,7 +1605,31 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.brec.reserve(std::max<uint64_t>(1, nbrec) * 4));
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[2], st));
   // ---- 3. rank on the matrix cores ----
-  {
+  if (ix.dim > kNarrowDim) {
+    const uint32_t nc = dq / 4;
+    VI_TRY(ws.qimg.reserve((uint64_t)nq * nc * 4 * 4));  // uint32 words: 4 pieces of 16 B per (query, chunk)
+    const uint64_t nt = (uint64_t)nq * nc * 2;
+    hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
+                       (uint4 *)ws.qimg.p);
+    const uint32_t nitems = (uint32_t)hstats[1];
+    VI_TRY(ws.item_list.reserve(std::max<uint32_t>(1, nitems)));
+    if (nitems) {
+      hipLaunchKernelGGL(item_list_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, ws.item_start.p, (uint32_t)nlists, nitems,
+                         ws.item_list.p);
+      WideArgs a{(const uint4 *)ix.lists_bf16.p, ix.xnorm_img.p, (const uint4 *)ws.qimg.p, nc, ix.list_first_block.p, ix.list_len.p,
+                 ws.item_start.p, ws.seg_start.p, ws.pairs.p, ws.item_list.p, P, segb0, ws.qoff.p, ws.pair_rel.p, ws.tile_start.p,
+                 (float4 *)ws.gval.p, ws.gpos.p, (float4 *)ws.brec.p};
+      static const bool attr = [] {
+        return hipFuncSetAttribute((const void *)rank_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kWideLdsFloats * (int)sizeof(float)) == hipSuccess;
+      }();
+      if (!attr) return fail(VI_ERR_DEVICE, "cannot reserve %d bytes of LDS for the wide rank kernel", kWideLdsFloats * 4);
+      hipLaunchKernelGGL(rank_wide_kernel, dim3(nitems), dim3(256), kWideLdsFloats * sizeof(float), st, a);
+    }
+    VI_HIP(hipGetLastError());
+    stt.rank_mode = 2;
+    stt.group_queries = gq;
+  } else {
     FilterArgs a{};
     a.blocks = rank_bf16() ? (const float4 *)ix.lists_bf16.p : (const float4 *)ix.lists.blocks.p;
     a.xnorm = rank_bf16() ? ix.xnorm_img.p : ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
@@ -1454,8 +1659,9 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
-    if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), 0, st, a);
+    const size_t qsm = 4ull * ix.dim * sizeof(float);
+    if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
+    else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));
