@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
-    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
   }
   // group records of the list phase: 2 per (probe, segment); query_offsets_kernel turns the per-query totals
   // into offsets
@@ -1171,19 +1171,24 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   const uint32_t K = a.P, nblk = (a.nlists + kWave - 1) / kWave, nrec = 4u * nblk;  // records: (block, tile, lane half)
   const size_t base = (size_t)(q / c.gq) * nblk * (4u * c.gq) + (q % c.gq);
   constexpr uint32_t kPer = kDirectBlocks * 4 / kWave;  // records per lane
-  float4 R[kPer];  // (min of sub-block 0 with its row, its second min, the same of sub-block 1)
-#pragma unroll
-  for (uint32_t i = 0; i < kPer; ++i) {
+  // (min of sub-block 0 with its row, its second min, the same of sub-block 1); read twice — for the bound, then for
+  // the flags (from L2 the second time) — rather than kept in 64 registers: one more wave per SIMD
+  auto record = [&](uint32_t i) {
     const uint32_t rec = i * kWave + lane;  // block rec >> 2, tile (rec >> 1) & 1, lane half rec & 1
-    R[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    if (rec < nrec) R[i] = c.brec[base + (size_t)(rec >> 2) * (4u * c.gq) + (size_t)((rec >> 1) & 1u) * (2u * c.gq) + c.gq * (rec & 1u)];
-  }
+    float4 r = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    if (rec < nrec) r = c.brec[base + (size_t)(rec >> 2) * (4u * c.gq) + (size_t)((rec >> 1) & 1u) * (2u * c.gq) + c.gq * (rec & 1u)];
+    return r;
+  };
   // bound of the K-th distance: every lane's smallest minimum belongs to a different centroid, so K centroids are at
   // or below the K-th smallest of the 64 lane minima — one 64-lane sort instead of a running top-K over all the minima
   // (K <= 64; the bound sits a few ranks above the exact K-th minimum, which costs a few more single-row evaluations)
   float lm = INFINITY;
 #pragma unroll
-  for (uint32_t i = 0; i < kPer; ++i) lm = min3_raw(lm, R[i].x, R[i].z);
+  for (uint32_t i = 0; i < kPer; ++i)
+    if (i * kWave < nrec) {
+      const float4 r = record(i);
+      lm = min3_raw(lm, r.x, r.z);
+    }
   WaveTopK s1;
   s1.init();
   s1 = offer_bulk_fn(s1, lm, (uint32_t)lane, (int)K);
@@ -1229,7 +1234,8 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   for (uint32_t i = 0; i < kPer; ++i)
     if (i * kWave < nrec) {
       const uint32_t rec = i * kWave + lane;
-      const float b1[2] = {R[i].x, R[i].z}, b2[2] = {R[i].y, R[i].w};
+      const float4 Ri = record(i);
+      const float b1[2] = {Ri.x, Ri.z}, b2[2] = {Ri.y, Ri.w};
 #pragma unroll
       for (uint32_t s2 = 0; s2 < 2; ++s2) {
         const bool cand = rec < nrec && !(b1[s2] > thr);
@@ -1262,7 +1268,7 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
-    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
   }
   uint32_t ng = 0;
   if (mylist != kNoPos) {
@@ -1456,8 +1462,8 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
-  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+  VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
   // one list, every query probes it: groups of 128 queries x segments of segb blocks

@@ -16,6 +16,12 @@ inline uint32_t layout_dq(uint32_t dim) { return ((dim + 15) / 16) * 4; }
 // (query, probe) pairs are counted / scattered per (list, query & 7): hot lists are probed by thousands of
 // queries of a batch and a single counter per list would serialise their atomics
 constexpr uint32_t kSubBins = 8;
+// counter of (list l, sub-bin s).  Sub-bin major, every sub-bin's row on cache lines of its own: the 8 counters of a
+// hot list must not share a line — atomics on one line execute one after the other at its L2 channel (the hottest lists
+// of a batch are probed by every query: 10 000 atomics on one line were 0.15 ms of the coarse select)
+__host__ __device__ inline uint32_t subbin_stride(uint32_t nlists) { return (nlists + 31u) & ~31u; }
+__host__ __device__ inline uint32_t subbin_index(uint32_t l, uint32_t s, uint32_t nlists) { return s * subbin_stride(nlists) + l; }
+inline uint64_t subbin_words(uint64_t nlists) { return (uint64_t)kSubBins * subbin_stride((uint32_t)nlists); }
 
 struct ScanArgs {
   const float4 *blocks;   // lane-interleaved blocks (device_index.hpp)

@@ -325,6 +325,7 @@ struct CoarseMergeArgs {
   uint32_t nq, S, P;              // P = entries per run = probes per query (<= 64), S <= 64
   const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt;
+  uint32_t nlists;
 };
 
 __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMergeArgs a) {
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = live ? mylist : kNoPos;
     a.gorder[(size_t)q * a.P + lane] = live ? g : kNoPos;
-    if (live && a.list_len[mylist] > 0) atomicAdd(&a.cnt[mylist * kSubBins + (q & (kSubBins - 1))], 1u);
+    if (live && a.list_len[mylist] > 0) atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
   }
 }
 
@@ -368,11 +369,12 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 //   item_start   Σ ceil(cnt/QG) * nseg      (scan work items)
 //   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
 // stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
-static_assert(kSubBins == 8, "group_scan_kernel reads a list's sub-bin counters as two uint4");
-__device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l) {
+// queries probing list l: the sum of its sub-bin counters (one coalesced load per sub-bin row)
+__device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l, uint32_t nlists) {
+  const uint32_t st = subbin_stride(nlists);
   uint32_t c = 0;
 #pragma unroll
-  for (uint32_t s = 0; s < kSubBins; ++s) c += cnt[l * kSubBins + s];
+  for (uint32_t s = 0; s < kSubBins; ++s) c += cnt[s * st + l];
   return c;
 }
 
@@ -386,12 +388,10 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   const int lane = t & 63, wave = t >> 6;
   const uint32_t per = (nlists + 1023) / 1024;
   const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
-  const uint4 *cnt4 = reinterpret_cast<const uint4 *>(cnt);  // kSubBins == 8: two uint4 per list
   uint32_t seg = 0, item = 0, run = 0, tile = 0;
   unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
   for (uint32_t l = beg; l < end; ++l) {
-    const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
-    const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+    const uint32_t c = list_count(cnt, l, nlists);
     const uint32_t len = list_len[l];
     uint32_t segb;
     const uint32_t ns = list_segments(len, segb0, &segb);
@@ -434,19 +434,19 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
   }
   uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
-  uint4 *cur4 = reinterpret_cast<uint4 *>(cursor);
+  const uint32_t cst = subbin_stride(nlists);
   for (uint32_t l = beg; l < end; ++l) {
-    const uint4 c0 = cnt4[2 * l], c1 = cnt4[2 * l + 1];
-    const uint32_t c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
     if (tile_start) tile_start[l] = rt;
     // each sub-bin scatters into its own slice of the list's segment
-    uint4 u0, u1;
-    u0.x = rs; u0.y = u0.x + c0.x; u0.z = u0.y + c0.y; u0.w = u0.z + c0.z;
-    u1.x = u0.w + c0.w; u1.y = u1.x + c1.x; u1.z = u1.y + c1.y; u1.w = u1.z + c1.z;
-    cur4[2 * l] = u0; cur4[2 * l + 1] = u1;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t sb = 0; sb < kSubBins; ++sb) {
+      cursor[sb * cst + l] = rs + c;
+      c += cnt[sb * cst + l];
+    }
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
     rt += ((c + qg - 1) / qg) * ns * ((segb + 1) / 2);
   }
@@ -467,7 +467,7 @@ __global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_le
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t l = probes[i];
-  if (l < nlists && list_len[l] > 0) atomicAdd(&cnt[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
+  if (l < nlists && list_len[l] > 0) atomicAdd(&cnt[subbin_index(l, (i / P) & (kSubBins - 1), nlists)], 1u);
 }
 
 __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t P,
@@ -477,7 +477,7 @@ __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *lis
   if (i >= total) return;
   const uint32_t l = probes[i];
   if (l >= nlists || list_len[l] == 0) return;
-  const uint32_t pos = atomicAdd(&cursor[l * kSubBins + ((i / P) & (kSubBins - 1))], 1u);
+  const uint32_t pos = atomicAdd(&cursor[subbin_index(l, (i / P) & (kSubBins - 1), nlists)], 1u);
   pairs[pos] = i;  // slot id = q*P + rank
   if (pair_pos) pair_pos[i] = pos - seg_start[l];  // MFMA path: where the pair sits among the pairs of its list
 }
@@ -1089,8 +1089,8 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
-  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+  VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
+  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
   const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
   const int qg_c = pick_qg(dq, (double)nq, ix.order);
   const uint32_t nqg = (uint32_t)((nq + qg_c - 1) / qg_c);
@@ -1108,7 +1108,7 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
   CoarseMergeArgs a{ws.crun_dist.p, ws.crun_pos.p, (uint32_t)nq, S, P, ix.list_shard.p, ix.list_len.p,
-                    ws.probes.p, ws.gorder.p, ws.cnt.p};
+                    ws.probes.p, ws.gorder.p, ws.cnt.p, (uint32_t)nlists};
   hipLaunchKernelGGL(coarse_merge_kernel, dim3((uint32_t)((nq + kWavesPerBlock - 1) / kWavesPerBlock)),
                      dim3(kBlockThreads), 0, st, a);
   VI_HIP(hipGetLastError());
@@ -1139,8 +1139,8 @@ vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uin
     return fail(VI_ERR_INVALID_INPUT, "probe lists out of range: every probe must be < %llu (or the empty marker 0xFFFFFFFF "
                 "after the last real probe of a row) and every order < n_probe_eff", (unsigned long long)nlists);
   if (histogram) {
-    VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
-    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+    VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
+    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p, ix.list_len.p,
                        (uint32_t)nlists, total, P, ws.cnt.p);
     VI_HIP(hipGetLastError());
@@ -1179,7 +1179,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + nlists * kSubBins, ws.stats.p, (uint32_t *)nullptr);
+                     ws.cnt.p + subbin_words(nlists), ws.stats.p, (uint32_t *)nullptr);
   VI_HIP(hipGetLastError());
   // exact work-item / segment-run counts size the scan grid and its scratch; the host waits for them while the
   // scatter runs
@@ -1189,7 +1189,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   {
     const uint32_t total = (uint32_t)(nq * P);
     hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws.probes.p,
-                       ix.list_len.p, (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total,
+                       ix.list_len.p, (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), ws.pairs.p, total,
                        ws.seg_start.p, (uint32_t *)nullptr);
     VI_HIP(hipGetLastError());
   }
@@ -1360,7 +1360,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
-  VI_TRY(ws.cnt.reserve(2 * nlists * kSubBins));
+  VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
   VI_TRY(ws.seg_start.reserve(nlists + 1));
   VI_TRY(ws.item_start.reserve(nlists + 1));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
@@ -1371,19 +1371,19 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
   VI_HIP(hipMemsetAsync(ws.stats.p + 12, 0, sizeof(uint64_t), st));
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
-    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, nlists * kSubBins * sizeof(uint32_t), st));
+    VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                        (uint32_t)nlists, total, P, ws.cnt.p);
   }
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
                      (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + nlists * kSubBins, ws.stats.p, ws.tile_start.p);
+                     ws.cnt.p + subbin_words(nlists), ws.stats.p, ws.tile_start.p);
   VI_HIP(hipGetLastError());
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.cur().ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
-                     (uint32_t)nlists, P, ws.cnt.p + nlists * kSubBins, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
+                     (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
   VI_HIP(hipGetLastError());
   VI_HIP(hipEventSynchronize(ix.cur().ev[5]));
   return VI_OK;
