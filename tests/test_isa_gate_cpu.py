@@ -67,7 +67,7 @@ def block_loop(body):
 def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
     ks = kernels(asm)
     assert len(ks) >= 16
-    dbl = {n: k for n, k in ks.items() if k["nbuf"] == 2}
+    dbl = {n: k for n, k in ks.items() if k["nbuf"] >= 2}
     assert dbl, "no double-buffered instantiation found"
     for name, k in ks.items():
         priv = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", k["meta"]).group(1))
@@ -84,4 +84,7 @@ def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
         assert not loads, f"{name}: plain global loads inside the block loop: {loads}"
         assert re.search(r"global_load_lds_dwordx4", loop), name
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)
-        assert "1" in waits and set(waits) <= ({"0", "1", "2"} if k["table"] else {"0", "1"}), f"{name}: vmcnt waits {waits}"
+        allowed = {"0", "1", "2"} if k["table"] else {"0", "1"}
+        if k["nbuf"] == 3:  # ring of three: the wait also leaves this iteration's LDS-DMA (<= 5 per wave) in flight
+            allowed = {str(i) for i in range(8)}
+        assert "1" in waits and set(waits) <= allowed, f"{name}: vmcnt waits {waits}"

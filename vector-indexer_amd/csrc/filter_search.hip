@@ -274,7 +274,7 @@ __device__ __forceinline__ float2 tile_min8_idx(const f32x16 &a, int r0) {
 template <int NG, int RANK, int NBUF, int WAVES>
 __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, const float *xn, int wave, int lane) {
   if constexpr (RANK != 2) {
-    if constexpr (NBUF == 2) tile_dma_image_asm<NG, WAVES>(tile, src, xn, wave, lane);  // the loop places its own waits
+    if constexpr (NBUF >= 2) tile_dma_image_asm<NG, WAVES>(tile, src, xn, wave, lane);  // the loop places its own waits
     else tile_dma_image<NG, WAVES>(tile, src, xn, wave, lane);
   } else {
 #pragma unroll
@@ -286,6 +286,21 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
       }
     }
     if (wave == 0) glds4_asm(xn + lane, tile + NG * 256);  // (asm: the double-buffered loop places its own waits)
+  }
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(uint32_t n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // (never asked for more than 7; a stricter wait is always safe)
   }
 }
 
@@ -381,18 +396,34 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   // tile_start counts the record tiles of the lists before this one: chunks x segments x seg_records
   const uint32_t bi = (a.tile_start[l] + (chunk * nseg + seg) * seg_records(segb)) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
 
+  // LDS-DMA instructions this wave issues per tile (RANK 2: its share of the NG hi pieces; wave 0 also the norms)
+  const uint32_t dma_ops = (RANK == 2 ? ((uint32_t)wave < (uint32_t)NG ? ((uint32_t)NG - (uint32_t)wave + WAVES - 1) / WAVES : 0u)
+                                      : (uint32_t)(2 * NG / WAVES)) + (wave == 0 ? 1u : 0u);
   tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
+  if (NBUF == 3 && b0 + 1 < b1 && !(a.xmode & 1u)) {  // ring of three: two tiles ahead
+    tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[1], a.blocks + ((size_t)(fb + b0 + 1) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0 + 1) * kWave, wave, lane);
+    wait_vmcnt(dma_ops);  // the first tile has landed, the second may still be on its way
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
+  }
   __syncthreads();                     // ... and so have everyone else's
+  uint32_t ring = 0;                   // buffer of the current block (NBUF == 3)
   for (uint32_t blk = b0; blk < b1; ++blk) {
     const bool more = (blk + 1 < b1) && !(a.xmode & 1u);
     uint32_t nstores = 0;  // record stores this lane issued in this iteration
-    const float *s_tile = s_tiles[NBUF == 2 ? ((blk - b0) & 1u) : 0];
+    const float *s_tile = s_tiles[NBUF == 3 ? ring : (NBUF == 2 ? ((blk - b0) & 1u) : 0)];
     // next block: lands in the other buffer during this block's MFMAs (every wave left that buffer at the
-    // barrier that ended the previous iteration)
+    // barrier that ended the previous iteration); with three buffers the block after the next is requested here, so
+    // that two tiles per workgroup are in flight (an experiment, VI_FILTER_NBUF=3: it measured equal)
+    uint32_t issued = 0;  // LDS-DMA instructions of this iteration (younger than the tile the block's end waits for)
     if (NBUF == 2 && more)
       tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[((blk - b0) & 1u) ^ 1u], a.blocks + ((size_t)(fb + blk + 1) * a.dq) * kWave,
                    a.xnorm + (size_t)(fb + blk + 1) * kWave, wave, lane);
+    if (NBUF == 3 && blk + 2 < b1 && !(a.xmode & 1u)) {
+      tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[ring >= 1 ? ring - 1 : 2], a.blocks + ((size_t)(fb + blk + 2) * a.dq) * kWave,
+                   a.xnorm + (size_t)(fb + blk + 2) * kWave, wave, lane);
+      issued = dma_ops;
+    }
     if (wave_live) {
       // both row tiles (vectors 0..31 and 32..63) advance together: two independent accumulator chains
       f32x16 acc0, acc1;
@@ -510,8 +541,12 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
       // Waiting for all but that store keeps the store's latency off the critical path; __syncthreads() would
       // insert vmcnt(0), hence the raw barrier (LDS reads of this tile are complete: lgkmcnt(0)).
       // (a store instruction is issued iff some lane of the wave stores: the ballots are the wave-uniform form of that)
-      if (__ballot(nstores == 2u) != 0ull) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (__ballot(nstores == 1u) != 0ull) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      const uint32_t st_ops = __ballot(nstores == 2u) != 0ull ? 2u : (__ballot(nstores == 1u) != 0ull ? 1u : 0u);
+      if (NBUF == 3) {
+        wait_vmcnt(issued + st_ops);  // everything but this iteration's DMA and stores: the NEXT block's tile has landed
+        ring = ring == 2 ? 0 : ring + 1;
+      } else if (st_ops == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (st_ops == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // next tile visible; this tile free to be overwritten
@@ -1285,6 +1320,13 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   if (lane == 63) a.qtot[q] = ig;
 }
 
+// a ring of three tile buffers (two tiles in flight per workgroup) for the hi-planes-only list ranking: measured equal to
+// two buffers on the bench workload (0.303 ms both: the launch is not waiting on the fabric), so off unless VI_FILTER_NBUF=3
+inline bool nbuf3_ok() {
+  const char *e = getenv("VI_FILTER_NBUF");
+  return e && *e == '3';
+}
+
 template <int NG>
 vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, uint32_t gq, hipStream_t st) {
   if (nitems == 0) return VI_OK;
@@ -1299,6 +1341,7 @@ vi_status launch_filter_t(const FilterArgs &a, uint32_t nitems, int rank_mode, u
     const dim3 block(256);
     if (rank_mode == 2) {  // half-size tiles: two buffers fit where one full image did, the next tile loads during the MFMAs
       if (table) hipLaunchKernelGGL((filter_kernel<NG, 2, true, 2, 128>), grid, block, 0, st, a);
+      else if (nbuf3_ok()) hipLaunchKernelGGL((filter_kernel<NG, 3, false, 2, 128>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((filter_kernel<NG, 2, false, 2, 128>), grid, block, 0, st, a);
     } else if (rank_mode == 1) {  // full images: one buffer, three workgroups per CU (two buffers cost the third: measured slower)
       if (table) hipLaunchKernelGGL((filter_kernel<NG, 1, true, 1, 128>), grid, block, 0, st, a);
