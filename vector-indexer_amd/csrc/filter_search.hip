@@ -225,6 +225,7 @@ struct FilterArgs {
   float4 *gval;                // group records: the four smallest sub-block minima of a (pair, segment, lane half)
   uint32_t *gmeta;             // ... and where the record belongs: probe rank | segment << 6 | lane half << 13
   float4 *brec;                // pair records: the sub-block minima of two blocks
+  const uint4 *qimg;  // -2 q of the batch split hi / lo once per search (split_queries_kernel), or null: split here
   uint32_t direct;  // coarse table only: records = the minima of the 8-row sub-blocks of every block, no group records
   uint32_t xmode;  // experiment knob (VI_FILTER_XMODE): 1 = do not restage tiles, 2 = no ranking epilogue
 };
@@ -289,6 +290,8 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
   }
 }
 
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out);
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
   switch (n) {
@@ -346,6 +349,9 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   const uint32_t nblk = (len + kWave - 1) / kWave;
   const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
 
+  // the first tile is requested before the queries are fetched: both latencies run together
+  tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
+
   // ---- this lane's query: both lane halves hold query j of the wave's tile ----
   // the tile a wave owns rotates with the item so that partially filled groups do not always idle the same SIMD
   const uint32_t wtile = ((uint32_t)wave + item) % (uint32_t)WAVES;
@@ -358,13 +364,23 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   float4 qf[NG];  // f32: -2q, dims 8g+4h.. ; BF16: qf[2c] = hi, qf[2c+1] = lo halves (bit patterns) of -2q, dims 16c+8h..
   constexpr bool BF16 = RANK != 0;
   bool q_lo_zero = false;  // RANK 2: every query of this wave splits with lo = 0
-  if constexpr (!BF16) {
+  if (!BF16) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const uint32_t e = 8 * g + 4 * h;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (qlive && e < a.dim) v = *reinterpret_cast<const float4 *>(qrow + e);
       qf[g] = make_float4(-2.f * v.x, -2.f * v.y, -2.f * v.z, -2.f * v.w);
+    }
+  } else if (a.qimg) {
+    // the batch's queries were split once (every query sits in n_probe work items): 16-byte pieces, no arithmetic here
+    const uint4 *qi = a.qimg + (size_t)qid * (NG / 2) * 4 + h;
+#pragma unroll
+    for (int c = 0; c < NG / 2; ++c) {
+      uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
+      if (qlive) { hi = qi[c * 4]; lo = qi[c * 4 + 2]; }
+      qf[2 * c] = __builtin_bit_cast(float4, hi);
+      qf[2 * c + 1] = __builtin_bit_cast(float4, lo);
     }
   } else {
 #pragma unroll
@@ -378,15 +394,15 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
       qf[2 * c] = __builtin_bit_cast(float4, hi);
       qf[2 * c + 1] = __builtin_bit_cast(float4, lo);
     }
-    if constexpr (RANK == 2) {
-      uint32_t any = 0;
+  }
+  if constexpr (RANK == 2) {
+    uint32_t any = 0;
 #pragma unroll
-      for (int c = 0; c < NG / 2; ++c) {
-        const uint4 lo = __builtin_bit_cast(uint4, qf[2 * c + 1]);
-        any |= lo.x | lo.y | lo.z | lo.w;
-      }
-      q_lo_zero = __ballot((any & 0x7FFF7FFFu) != 0u) == 0ull;  // (-0 halves are zero too)
+    for (int c = 0; c < NG / 2; ++c) {
+      const uint4 lo = __builtin_bit_cast(uint4, qf[2 * c + 1]);
+      any |= lo.x | lo.y | lo.z | lo.w;
     }
+    q_lo_zero = __ballot((any & 0x7FFF7FFFu) != 0u) == 0ull;  // (-0 halves are zero too)
   }
 
   float T0 = INFINITY, T1 = INFINITY, T2 = INFINITY, T3 = INFINITY;  // four smallest sub-block minima of the segment
@@ -399,7 +415,6 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   // LDS-DMA instructions this wave issues per tile (RANK 2: its share of the NG hi pieces; wave 0 also the norms)
   const uint32_t dma_ops = (RANK == 2 ? ((uint32_t)wave < (uint32_t)NG ? ((uint32_t)NG - (uint32_t)wave + WAVES - 1) / WAVES : 0u)
                                       : (uint32_t)(2 * NG / WAVES)) + (wave == 0 ? 1u : 0u);
-  tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
   if (NBUF == 3 && b0 + 1 < b1 && !(a.xmode & 1u)) {  // ring of three: two tiles ahead
     tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[1], a.blocks + ((size_t)(fb + b0 + 1) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0 + 1) * kWave, wave, lane);
     wait_vmcnt(dma_ops);  // the first tile has landed, the second may still be on its way
@@ -1543,6 +1558,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.direct = direct ? 1u : 0u;
+    a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
@@ -1579,9 +1595,23 @@ static uint32_t list_segb0() {
   return sb ? (uint32_t)std::max(1, atoi(sb)) : 32u;  // <= 2048 vectors per work item
 }
 
+// the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
+static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint64_t nq, hipStream_t st) {
+  if (!rank_bf16()) return VI_OK;
+  SearchWorkspace &ws = ix.cur().ws;
+  const uint32_t nc = ix.dq / 4;
+  VI_TRY(ws.qimg.reserve((uint64_t)nq * nc * 4 * 4));  // uint32 words: 4 pieces of 16 B per (query, chunk)
+  const uint64_t nt = (uint64_t)nq * nc * 2;
+  hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
+                     (uint4 *)ws.qimg.p);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
 // coarse step alone on the matrix cores (probe export for other ranks): fills ws.probes / ws.gorder
 vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
   SearchWorkspace &ws = ix.cur().ws;
+  VI_TRY(build_query_image(ix, Qd, nq, st));
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   return stage_coarse_filter(ix, Qd, nq, P, list_segb0(), st);
@@ -1602,6 +1632,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.stats.reserve(16));
   if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
+  // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
+  VI_TRY(build_query_image(ix, Qd, nq, st));
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
     const char *cf = getenv("VI_COARSE_FILTER");
@@ -1656,10 +1688,6 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // ---- 3. rank on the matrix cores ----
   if (ix.dim > kNarrowDim) {
     const uint32_t nc = dq / 4;
-    VI_TRY(ws.qimg.reserve((uint64_t)nq * nc * 4 * 4));  // uint32 words: 4 pieces of 16 B per (query, chunk)
-    const uint64_t nt = (uint64_t)nq * nc * 2;
-    hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
-                       (uint4 *)ws.qimg.p);
     const uint32_t nitems = (uint32_t)hstats[1];
     VI_TRY(ws.item_list.reserve(std::max<uint32_t>(1, nitems)));
     if (nitems) {
@@ -1696,6 +1724,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.item_list = ws.item_list.p;
     a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
+    a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
     const int rank_mode = rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0;
     stt.rank_mode = (uint64_t)rank_mode + 1;
     stt.group_queries = gq;
