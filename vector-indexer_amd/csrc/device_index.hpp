@@ -64,6 +64,7 @@ struct SearchWorkspace {
   uint64_t c_nq = 0;                        // ... for this batch size
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
   DevBuf<uint32_t> item_list;               // list of each rank work item
+  DevBuf<uint32_t> items;                   // ... or its whole descriptor (8 words), item_desc_kernel
   DevBuf<uint32_t> tile_start, pair_pos;    // pair records: first record tile of each list; position of a (query, probe) pair in its list
   DevBuf<float> gval;                       // group records: 4 smallest sub-block minima per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and where each record belongs (probe rank | segment | lane half)

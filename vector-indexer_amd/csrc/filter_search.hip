@@ -203,6 +203,31 @@ __global__ void item_list_kernel(const uint32_t *item_start, uint32_t nlists, ui
   item_list[item] = lo;
 }
 
+// everything a list-rank work item needs to know about itself, 32 bytes it reads with two wave-uniform loads instead
+// of a chain of five dependent ones (list -> offsets -> length -> ...) at the head of every workgroup:
+// {first pair, queries, first block of the list, b0, b1, segment, first record tile, -}
+__global__ void item_desc_kernel(const uint32_t *item_start, const uint32_t *seg_start, const uint32_t *list_len,
+                                 const uint32_t *first_block, const uint32_t *tile_start, uint32_t nlists, uint32_t nitems,
+                                 uint32_t segb0, uint32_t gq, uint4 *items) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= nitems) return;
+  uint32_t lo = 0, hi = nlists;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (item_start[mid] <= item) lo = mid; else hi = mid;
+  }
+  const uint32_t l = lo;
+  const uint32_t s0 = seg_start[l], cnt = seg_start[l + 1] - s0, len = list_len[l];
+  uint32_t segb;
+  const uint32_t nseg = list_segments(len, segb0, &segb);
+  const uint32_t local = item - item_start[l];
+  const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
+  const uint32_t j0 = chunk * gq;
+  const uint32_t nblk = (len + 63u) / 64u, b0 = seg * segb, b1 = min(nblk, b0 + segb);
+  items[2 * (size_t)item] = make_uint4(s0 + j0, min(gq, cnt - j0), first_block[l], b0);
+  items[2 * (size_t)item + 1] = make_uint4(b1, seg, tile_start[l] + (chunk * nseg + seg) * seg_records(segb), 0u);
+}
+
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -222,6 +247,7 @@ struct FilterArgs {
   uint32_t rec_stride;         // ... or a fixed number of records per slot when qoff is null (coarse table)
   const uint32_t *tile_start;  // pair records: first record tile (2 * GQ records) of each list
   const uint32_t *item_list;   // list of each work item (null: binary search over item_start)
+  const uint4 *items;          // list phase: the work items' descriptors (item_desc_kernel), or null: derived here
   float4 *gval;                // group records: the four smallest sub-block minima of a (pair, segment, lane half)
   uint32_t *gmeta;             // ... and where the record belongs: probe rank | segment << 6 | lane half << 13
   float4 *brec;                // pair records: the sub-block minima of two blocks
@@ -326,28 +352,42 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const uint32_t item = blockIdx.x;  // grid == number of items
-  uint32_t lo = 0;
-  if (a.item_list) {
-    lo = a.item_list[item];
+  uint32_t pair0, nqi, fb, b0, b1, seg, rec0, chunk = 0, nblk = 0;
+  if (!TABLE && a.items) {
+    const uint4 d0 = a.items[2 * (size_t)item], d1 = a.items[2 * (size_t)item + 1];
+    pair0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0.x); nqi = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0.y);
+    fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0.z); b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d0.w);
+    b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d1.x); seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)d1.y);
+    rec0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d1.z);
   } else {
-    uint32_t hi = a.nlists;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (a.item_start[mid] <= item) lo = mid; else hi = mid;
+    uint32_t lo = 0;
+    if (a.item_list) {
+      lo = a.item_list[item];
+    } else {
+      uint32_t hi = a.nlists;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.item_start[mid] <= item) lo = mid; else hi = mid;
+      }
     }
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
+    const uint32_t len = a.list_len[l];
+    uint32_t segb;
+    const uint32_t nseg = list_segments(len, a.segb0, &segb);
+    const uint32_t local = item - a.item_start[l];
+    chunk = local / nseg;
+    seg = local - chunk * nseg;
+    const uint32_t j0 = chunk * GQ;
+    pair0 = s0 + j0;
+    nqi = min((uint32_t)GQ, cnt - j0);
+    fb = a.first_block[l];
+    nblk = (len + kWave - 1) / kWave;
+    b0 = seg * segb;
+    b1 = min(nblk, b0 + segb);
+    // tile_start counts the record tiles of the lists before this one: chunks x segments x seg_records
+    rec0 = a.tile_start[l] + (chunk * nseg + seg) * seg_records(segb);
   }
-  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-  const uint32_t s0 = a.seg_start[l], cnt = a.seg_start[l + 1] - s0;
-  const uint32_t len = a.list_len[l];
-  uint32_t segb;
-  const uint32_t nseg = list_segments(len, a.segb0, &segb);
-  const uint32_t local = item - a.item_start[l];
-  const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
-  const uint32_t j0 = chunk * GQ;
-  const uint32_t nqi = min((uint32_t)GQ, cnt - j0);
-  const uint32_t fb = a.first_block[l];
-  const uint32_t nblk = (len + kWave - 1) / kWave;
-  const uint32_t b0 = seg * segb, b1 = min(nblk, b0 + segb);
 
   // the first tile is requested before the queries are fetched: both latencies run together
   tile_dma_rank<NG, RANK, NBUF, WAVES>(s_tiles[0], a.blocks + ((size_t)(fb + b0) * a.dq) * kWave, a.xnorm + (size_t)(fb + b0) * kWave, wave, lane);
@@ -358,7 +398,7 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   const uint32_t jq_grp = 32u * wtile + (uint32_t)j;
   const bool qlive = jq_grp < nqi;
   const bool wave_live = 32u * wtile < nqi;  // wave-uniform
-  const uint32_t slot = qlive ? a.pairs[s0 + j0 + jq_grp] : 0u;
+  const uint32_t slot = qlive ? a.pairs[pair0 + jq_grp] : 0u;
   const uint32_t qid = slot / a.P;
   const float *qrow = a.Q + (size_t)qid * a.dim;
   float4 qf[NG];  // f32: -2q, dims 8g+4h.. ; BF16: qf[2c] = hi, qf[2c+1] = lo halves (bit patterns) of -2q, dims 16c+8h..
@@ -409,8 +449,7 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
   float4 w = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);    // the pair record being filled
   // pair records are item-major — [record tile = (query group, segment, pair of blocks)][lane half][query of the
   // group] — so that a wave's 32 queries store 512 contiguous bytes (record counts are checked < 2^32 on the host);
-  // tile_start counts the record tiles of the lists before this one: chunks x segments x seg_records
-  const uint32_t bi = (a.tile_start[l] + (chunk * nseg + seg) * seg_records(segb)) * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
+  const uint32_t bi = rec0 * (2u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
 
   // LDS-DMA instructions this wave issues per tile (RANK 2: its share of the NG hi pieces; wave 0 also the norms)
   const uint32_t dma_ops = (RANK == 2 ? ((uint32_t)wave < (uint32_t)NG ? ((uint32_t)NG - (uint32_t)wave + WAVES - 1) / WAVES : 0u)
@@ -1716,12 +1755,15 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     a.tile_start = ws.tile_start.p;
     const uint32_t nitems = (uint32_t)hstats[1];
     VI_TRY(ws.item_list.reserve(std::max<uint32_t>(1, nitems)));
+    VI_TRY(ws.items.reserve(std::max<uint32_t>(1, nitems) * 8ull));
     if (nitems) {
-      hipLaunchKernelGGL(item_list_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, ws.item_start.p,
-                         (uint32_t)nlists, nitems, ws.item_list.p);
+      hipLaunchKernelGGL(item_desc_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, ws.item_start.p, ws.seg_start.p,
+                         ix.list_len.p, ix.list_first_block.p, ws.tile_start.p, (uint32_t)nlists, nitems, segb0, gq,
+                         (uint4 *)ws.items.p);
       VI_HIP(hipGetLastError());
     }
-    a.item_list = ws.item_list.p;
+    a.item_list = nullptr;
+    a.items = (const uint4 *)ws.items.p;
     a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
     a.xmode = env_xmode();
     a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
