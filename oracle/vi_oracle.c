@@ -7,6 +7,7 @@
  */
 #define _GNU_SOURCE
 #include "vi_oracle.h"
+#include "../include/vi_reduce_order.h"
 
 #include <errno.h>
 #include <math.h>
@@ -96,10 +97,11 @@ float orc_l2sq_simd(const float *p, const float *c, size_t d) {
     tail = tail + t * t;
     j += 1;
   }
-  float lo = ((a8[0] + a8[1]) + a8[2]) + a8[3];
-  float hi = ((a8[4] + a8[5]) + a8[6]) + a8[7];
+  /* lane order of wide's reduce_add: include/vi_reduce_order.h (shared with the product; unpinned) */
+  float lo = VI_REDUCE4(a8[0], a8[1], a8[2], a8[3]);
+  float hi = VI_REDUCE4(a8[4], a8[5], a8[6], a8[7]);
   float r8 = lo + hi;
-  float r4 = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+  float r4 = VI_REDUCE4(a4[0], a4[1], a4[2], a4[3]);
   return (r8 + r4) + tail;
 }
 

@@ -12,7 +12,15 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workload = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1_000_000, 128, 4096, 32, 10_000, 10]
-kt = glob.glob(f"gpurun_out/prof_{tag}_kt/*/*_kernel_stats.csv")[0]
+import os
+
+
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: take the most recent profile"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+kt = newest(f"gpurun_out/prof_{tag}_kt/*/*_kernel_stats.csv")
 shutil.copy(kt, f"profiles/{tag}_bench_kernel_stats.csv")
 
 
@@ -21,7 +29,7 @@ KERNEL = r"filter_kernel<\d+, \d+, false, \d+, \d+>|scan_kernel<\d+, 0, false, f
 
 
 def scan_avg(pattern, counter):
-    f = glob.glob(pattern)[0]
+    f = newest(pattern)
     rows = [r for r in csv.DictReader(open(f)) if re.search(KERNEL, r["Kernel_Name"])
             and r["Counter_Name"] == counter]
     rows = [r for r in rows if r["Kernel_Name"] == rows[-1]["Kernel_Name"]]  # the timed steps' instantiation

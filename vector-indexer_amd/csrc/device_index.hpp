@@ -44,6 +44,7 @@ struct SearchWorkspace {
   DevBuf<uint32_t> gorder;      // [nq][P] candidate-order rank of each probe (shard visiting order)
   DevBuf<uint32_t> probe_flag;  // validation result of caller-supplied probe lists
   DevBuf<uint32_t> cnt;         // [nlists] (#queries probing list) ; cursor = second half
+  DevBuf<uint32_t> list_tot;    // [nlists] queries probing each list
   DevBuf<uint32_t> seg_start;   // [nlists+1]
   DevBuf<uint32_t> item_start;  // [nlists+1]
   DevBuf<uint32_t> segrun_start;  // [nlists+1]

@@ -5,6 +5,8 @@
 
 #include <cstdint>
 
+#include "../../include/vi_reduce_order.h"
+
 namespace vi {
 
 __device__ __forceinline__ void sq_add(float &acc, float q, float x) {
@@ -30,9 +32,9 @@ __device__ __forceinline__ float l2sq_lanes_dev(const float *p, const float *c, 
 #pragma unroll
     for (int l = 0; l < 4; ++l) sq_add(a4[l], p[j + l], c[j + l]);
   for (; j < d; ++j) sq_add(tail, p[j], c[j]);
-  const float lo = ((a8[0] + a8[1]) + a8[2]) + a8[3];
-  const float hi = ((a8[4] + a8[5]) + a8[6]) + a8[7];
-  const float r4 = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+  const float lo = VI_REDUCE4(a8[0], a8[1], a8[2], a8[3]);  // lane order: include/vi_reduce_order.h (unpinned)
+  const float hi = VI_REDUCE4(a8[4], a8[5], a8[6], a8[7]);
+  const float r4 = VI_REDUCE4(a4[0], a4[1], a4[2], a4[3]);
   return ((lo + hi) + r4) + tail;
 }
 

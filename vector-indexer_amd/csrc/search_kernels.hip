@@ -108,9 +108,9 @@ struct Acc<VI_ORDER_LANES, QG> {
     }
   }
   __device__ __forceinline__ float finish(int j) const {
-    const float lo = ((a8[j][0] + a8[j][1]) + a8[j][2]) + a8[j][3];
-    const float hi = ((a8[j][4] + a8[j][5]) + a8[j][6]) + a8[j][7];
-    const float r4 = ((a4[j][0] + a4[j][1]) + a4[j][2]) + a4[j][3];
+    const float lo = VI_REDUCE4(a8[j][0], a8[j][1], a8[j][2], a8[j][3]);  // include/vi_reduce_order.h
+    const float hi = VI_REDUCE4(a8[j][4], a8[j][5], a8[j][6], a8[j][7]);
+    const float r4 = VI_REDUCE4(a4[j][0], a4[j][1], a4[j][2], a4[j][3]);
     return ((lo + hi) + r4) + tail[j];
   }
 };
@@ -364,24 +364,39 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 // ------------------------------------------------------------------------------------------
 // grouping (counting sort of (query, probe) pairs by list)
 // ------------------------------------------------------------------------------------------
-// single block: exclusive scans over the lists of
+// single block (cnt = the per-list totals of list_totals_kernel): exclusive scans over the lists of
 //   seg_start    Σ cnt                      (pairs grouped by list)
 //   item_start   Σ ceil(cnt/QG) * nseg      (scan work items)
 //   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
 // stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
-// queries probing list l: the sum of its sub-bin counters (one coalesced load per sub-bin row)
-__device__ __forceinline__ uint32_t list_count(const uint32_t *cnt, uint32_t l, uint32_t nlists) {
+// queries probing every list: the sum of its sub-bin counters (one thread per list: coalesced along each sub-bin row)
+__global__ void list_totals_kernel(const uint32_t *cnt, uint32_t nlists, uint32_t *tot) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlists) return;
   const uint32_t st = subbin_stride(nlists);
   uint32_t c = 0;
 #pragma unroll
   for (uint32_t s = 0; s < kSubBins; ++s) c += cnt[s * st + l];
-  return c;
+  tot[l] = c;
+}
+
+// where each sub-bin of a list scatters to: its own slice of the list's segment of `pairs`
+__global__ void cursor_kernel(const uint32_t *cnt, const uint32_t *seg_start, uint32_t nlists, uint32_t *cursor) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlists) return;
+  const uint32_t st = subbin_stride(nlists);
+  uint32_t run = seg_start[l];
+#pragma unroll
+  for (uint32_t s = 0; s < kSubBins; ++s) {
+    cursor[s * st + l] = run;
+    run += cnt[s * st + l];
+  }
 }
 
 __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
                                                           uint32_t nlists, uint32_t qg, uint32_t segb0,
                                                           uint32_t *seg_start, uint32_t *item_start,
-                                                          uint32_t *segrun_start, uint32_t *cursor, uint64_t *stats,
+                                                          uint32_t *segrun_start, uint64_t *stats,
                                                           uint32_t *tile_start) {
   __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
   const uint32_t t = threadIdx.x;
@@ -391,7 +406,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   uint32_t seg = 0, item = 0, run = 0, tile = 0;
   unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
   for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = list_count(cnt, l, nlists);
+    const uint32_t c = cnt[l];  // (per-list totals: list_totals_kernel)
     const uint32_t len = list_len[l];
     uint32_t segb;
     const uint32_t ns = list_segments(len, segb0, &segb);
@@ -434,19 +449,12 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
   }
   uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
-  const uint32_t cst = subbin_stride(nlists);
   for (uint32_t l = beg; l < end; ++l) {
     uint32_t segb;
     const uint32_t ns = list_segments(list_len[l], segb0, &segb);
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
     if (tile_start) tile_start[l] = rt;
-    // each sub-bin scatters into its own slice of the list's segment
-    uint32_t c = 0;
-#pragma unroll
-    for (uint32_t sb = 0; sb < kSubBins; ++sb) {
-      cursor[sb * cst + l] = rs + c;
-      c += cnt[sb * cst + l];
-    }
+    const uint32_t c = cnt[l];
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
     rt += ((c + qg - 1) / qg) * ns * ((segb + 1) / 2);
   }
@@ -1084,6 +1092,20 @@ vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, ui
 // ------------------------------------------------------------------------------------------
 // pipeline stages
 // ------------------------------------------------------------------------------------------
+// histogram (ws.cnt) -> totals -> offsets of the lists in pairs / items / records -> scatter cursors
+static vi_status launch_group_scan(const DeviceIndex &ix, uint32_t qg, uint32_t segb0, uint32_t *tile_start, hipStream_t st) {
+  SearchWorkspace &ws = ix.cur().ws;
+  const uint32_t nlists = (uint32_t)ix.nlists;
+  VI_TRY(ws.list_tot.reserve(std::max<uint32_t>(1, nlists)));
+  const dim3 grid((nlists + 255) / 256), block(256);
+  hipLaunchKernelGGL(list_totals_kernel, grid, block, 0, st, ws.cnt.p, nlists, ws.list_tot.p);
+  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.list_tot.p, ix.list_len.p, nlists, qg, segb0,
+                     ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p, tile_start);
+  hipLaunchKernelGGL(cursor_kernel, grid, block, 0, st, ws.cnt.p, ws.seg_start.p, nlists, ws.cnt.p + subbin_words(nlists));
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
 // 1+2: coarse scan over the centroid table, merge -> ws.probes / ws.gorder, histogram in ws.cnt
 vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
   SearchWorkspace &ws = ix.cur().ws;
@@ -1177,10 +1199,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   VI_TRY(ws.pairs.reserve(nq * P));
   VI_TRY(ws.segrun_start.reserve(nlists + 1));
   VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg_l, kSegBlocks, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + subbin_words(nlists), ws.stats.p, (uint32_t *)nullptr);
-  VI_HIP(hipGetLastError());
+  VI_TRY(launch_group_scan(ix, (uint32_t)qg_l, kSegBlocks, nullptr, st));
   // exact work-item / segment-run counts size the scan grid and its scratch; the host waits for them while the
   // scatter runs
   uint64_t hstats[3] = {0, 0, 0};
@@ -1375,10 +1394,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                        (uint32_t)nlists, total, P, ws.cnt.p);
   }
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.cnt.p, ix.list_len.p, (uint32_t)nlists,
-                     (uint32_t)qg, segb0, ws.seg_start.p, ws.item_start.p, ws.segrun_start.p,
-                     ws.cnt.p + subbin_words(nlists), ws.stats.p, ws.tile_start.p);
-  VI_HIP(hipGetLastError());
+  VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st));
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.cur().ev[5], st));
