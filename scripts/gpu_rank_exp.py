@@ -63,7 +63,37 @@ SETTINGS = [
     ("select: stage 1a only (s7)", {"VI_SELECT_XMODE": 7}),
     ("segb 16", {"VI_FILTER_SEGB": 16}),
     ("segb 64", {"VI_FILTER_SEGB": 64}),
+    ("x16 prologue only", {"VI_FILTER_XMODE": 16}),
+    ("x48 prologue without gather", {"VI_FILTER_XMODE": 48}),
+    ("gq256", {"VI_STREAM_GQ": 256}),
+    ("gq256 x1", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 1}),
+    ("gq256 x16", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 16}),
+    ("gq256 segb 16", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 16}),
+    ("gq256 segb 64", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 64}),
+    ("gq256 segb 128", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 128}),
+    ("gq128 segb 64", {"VI_STREAM_GQ": 128, "VI_FILTER_SEGB": 64}),
+    ("gq128 segb 128", {"VI_STREAM_GQ": 128, "VI_FILTER_SEGB": 128}),
+    ("gq256 1 wg/cu", {"VI_STREAM_GQ": 256, "VI_STREAM_WGS_PER_CU": 1}),
+    ("gq256 4 wg/cu", {"VI_STREAM_GQ": 256, "VI_STREAM_WGS_PER_CU": 4}),
+    ("gq128 1 wg/cu", {"VI_STREAM_GQ": 128, "VI_STREAM_WGS_PER_CU": 1}),
+    ("gq256 x2 no epilogue", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 2}),
+    ("gq256 x3", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 3}),
+    ("gq256 x64 static", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 64}),
+    ("gq256 x32 no gather", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 32}),
+    ("gq256 x96", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 96}),
+    ("gq256 x80", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 80}),
+    ("gq128", {"VI_STREAM_GQ": 128}),
+    ("old kernel", {"VI_RANK_STREAM": 0}),
+    ("run 1", {"VI_ITEM_RUN": 1}),
+    ("run 4", {"VI_ITEM_RUN": 4}),
+    ("run 16", {"VI_ITEM_RUN": 16}),
+    ("run 32", {"VI_ITEM_RUN": 32}),
+    ("run 16 no epilogue", {"VI_ITEM_RUN": 16, "VI_FILTER_XMODE": 2}),
+    ("run 16 segb 64", {"VI_ITEM_RUN": 16, "VI_FILTER_SEGB": 64}),
 ]
+if os.environ.get("SET"):  # SET=a,b,c: only these settings (prefix match)
+    want = os.environ["SET"].split(",")
+    SETTINGS = [s for s in SETTINGS if any(s[0].startswith(w) for w in want)]
 only = os.environ.get("EXP")
 probes = [int(a) for a in sys.argv[1:]] or [16, 32]
 for p in probes:

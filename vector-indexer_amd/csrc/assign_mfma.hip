@@ -41,7 +41,6 @@
 namespace vi {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTileC = 64;          // centroids per LDS tile
 constexpr int kRowStride = 132;     // floats per LDS row (528 B: conflict-free b128 reads)

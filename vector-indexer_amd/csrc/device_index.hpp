@@ -66,6 +66,8 @@ struct SearchWorkspace {
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
   DevBuf<uint32_t> item_list;               // list of each rank work item
   DevBuf<uint32_t> items;                   // ... or its whole descriptor (8 words), item_desc_kernel
+  DevBuf<uint64_t> prof;                    // diagnostic counters (VI_STREAM_PROF)
+  DevBuf<uint32_t> item_qcol, item_grec, item_sdesc;    // streaming rank kernel: per (item, column) the query / its group record (item_cols_kernel)
   DevBuf<uint32_t> tile_start, pair_pos;    // pair records: first record tile of each list; position of a (query, probe) pair in its list
   DevBuf<float> gval;                       // group records: 4 smallest sub-block minima per (query, probe, segment, lane half)
   DevBuf<uint32_t> gpos;                    // ... and where each record belongs (probe rank | segment | lane half)
@@ -73,6 +75,8 @@ struct SearchWorkspace {
   DevBuf<float> brec;                       // pair records: the 4 sub-block minima of two blocks per (record tile, lane half, query of the group)
   struct GqHint { uint64_t nq; uint32_t P, gq; };
   std::vector<GqHint> gq_hint;              // queries per rank work item measured to suit a batch shape (filter_search.hip)
+  bool stats_zeroed = false;                // stats[13], [14] start at zero (filter_search.hip)
+  bool queries_hi_only = false;             // the previous batch's -2 q were all bf16-exact (no lo plane)
   DevBuf<uint64_t> sort_keys, order_keys, total;
   DevBuf<uint32_t> gprobe, off_by_g, off_by_rank;
 };

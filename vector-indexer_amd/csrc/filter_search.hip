@@ -46,6 +46,7 @@
 #include "device_index.hpp"
 #include "device_math.hpp"
 #include "mfma_bf16.hpp"
+#include "rank_stream.hpp"
 #include "scan.hpp"
 #include "wave_select.hpp"
 
@@ -56,19 +57,15 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
 vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
                        bool histogram, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[13], hipStream_t st, bool histogram_done);
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done);
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWave = 64;
 constexpr uint32_t kMaxFilterDim = 1536;  // the MFMA engine's dimension limit (rank_wide_kernel above 128)
 constexpr int kGroupQ = 128;       // queries per work item: 4 waves x one MFMA column tile of 32
 constexpr uint32_t kPosBits = 26;  // candidate key = (probe rank << 26) | position in list
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
-// pair records of one list segment of segb blocks (every segment of a list reserves the same number)
-__host__ __device__ inline uint32_t seg_records(uint32_t segb) { return (segb + 1u) / 2u; }
 constexpr float kBig = 3.0e38f;            // norm of pad slots inside the kernel (finite: low bits are reused)
 
 __global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, float *xnorm, uint32_t *xmax_bits) {
@@ -206,11 +203,24 @@ __global__ void item_list_kernel(const uint32_t *item_start, uint32_t nlists, ui
 // everything a list-rank work item needs to know about itself, 32 bytes it reads with two wave-uniform loads instead
 // of a chain of five dependent ones (list -> offsets -> length -> ...) at the head of every workgroup:
 // {first pair, queries, first block of the list, b0, b1, segment, first record tile, -}
+// Workgroup -> item: the hardware deals workgroups to the 8 XCDs round-robin (workgroup w runs on XCD w % 8), and each
+// XCD has its own L2.  The query groups of one list segment stream the SAME blocks, so they are numbered next to each
+// other (segment-major) and dealt in runs of `run` items to one XCD: workgroup w = (cycle, r, x) -> item
+// cycle * 8 run + x * run + r.  They start together, the followers hit the L2 lines the first one brought in, and a
+// hit is faster than a miss, which keeps them together.  (run <= 1: workgroup w takes item w.)
 __global__ void item_desc_kernel(const uint32_t *item_start, const uint32_t *seg_start, const uint32_t *list_len,
                                  const uint32_t *first_block, const uint32_t *tile_start, uint32_t nlists, uint32_t nitems,
-                                 uint32_t segb0, uint32_t gq, uint4 *items) {
-  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= nitems) return;
+                                 uint32_t segb0, uint32_t gq, uint32_t run, uint4 *items) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nitems) return;
+  uint32_t item = w;
+  if (run > 1u) {
+    const uint32_t span = 8u * run, cycle = w / span;
+    if ((cycle + 1u) * span <= nitems) {  // (the last, partial cycle keeps its order)
+      const uint32_t in = w - cycle * span;
+      item = cycle * span + (in & 7u) * run + (in >> 3);
+    }
+  }
   uint32_t lo = 0, hi = nlists;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -221,11 +231,39 @@ __global__ void item_desc_kernel(const uint32_t *item_start, const uint32_t *seg
   uint32_t segb;
   const uint32_t nseg = list_segments(len, segb0, &segb);
   const uint32_t local = item - item_start[l];
-  const uint32_t chunk = local / nseg, seg = local - chunk * nseg;
+  const uint32_t nchunk = (cnt + gq - 1u) / gq;  // query groups of the list: its items are nchunk * nseg
+  const uint32_t seg = local / nchunk, chunk = local - seg * nchunk;
   const uint32_t j0 = chunk * gq;
   const uint32_t nblk = (len + 63u) / 64u, b0 = seg * segb, b1 = min(nblk, b0 + segb);
-  items[2 * (size_t)item] = make_uint4(s0 + j0, min(gq, cnt - j0), first_block[l], b0);
-  items[2 * (size_t)item + 1] = make_uint4(b1, seg, tile_start[l] + (chunk * nseg + seg) * seg_records(segb), 0u);
+  items[2 * (size_t)w] = make_uint4(s0 + j0, min(gq, cnt - j0), first_block[l], b0);
+  items[2 * (size_t)w + 1] = make_uint4(b1, seg, tile_start[l] + (chunk * nseg + seg) * seg_records(segb), 0u);
+}
+
+// Per (work item, column of its query group): the query, and where its group record goes — so that the rank
+// workgroup finds everything about an item at addresses it can compute from the item's index alone (no chain
+// descriptor -> pairs -> query offsets at the head of every item) — and the place word of the pair's two group records
+// (probe rank | segment << 6 | lane half << 13; every (pair, segment) sits in exactly one item).  One workgroup per
+// item; workgroup 0 also resets the rank kernel's work counter and the "a query has a lo plane" flag of the next batch.
+__global__ void item_cols_kernel(const uint4 *items, const uint32_t *pairs, const uint32_t *qoff, const uint32_t *rel, uint32_t P,
+                                 uint32_t gq, uint32_t *qcol, uint32_t *grec, uint4 *sdesc, uint32_t *gmeta, uint64_t *stats) {
+  const uint32_t w = blockIdx.x;
+  const uint4 d0 = items[2 * (size_t)w], d1 = items[2 * (size_t)w + 1];
+  if (threadIdx.x == 0) {
+    sdesc[w] = make_uint4(d0.y, d0.z + d0.w, 2u * (d1.x - d0.w), d1.z);  // queries, first block, tiles, first record tile
+    if (w == 0) { stats[13] = 0; stats[14] = 0; }
+  }
+  for (uint32_t col = threadIdx.x; col < gq; col += blockDim.x) {
+    uint32_t q = ~0u, g = ~0u;
+    if (col < d0.y) {
+      const uint32_t slot = pairs[d0.x + col];
+      q = slot / P;
+      g = qoff[q] + rel[slot] + 2u * d1.y;
+      const uint32_t place = (slot - q * P) | (d1.y << 6);
+      *reinterpret_cast<uint2 *>(gmeta + g) = make_uint2(place, place | (1u << 13));  // (g is even: 8-byte aligned)
+    }
+    qcol[(size_t)w * gq + col] = q;
+    grec[(size_t)w * gq + col] = g;
+  }
 }
 
 __global__ void iota_kernel(uint32_t *p, uint32_t n) {
@@ -263,19 +301,6 @@ struct FilterArgs {
 // followed by the block's 64 squared norms.  With NBUF = 2 the next block lands in the other buffer while
 // this one is multiplied (one barrier per block); with NBUF = 1 the load is exposed and hidden by the other
 // workgroups of the CU (3 per CU instead of 2).
-// minimum of three without the canonicalising v_max the compiler puts in front of fminf on values it cannot prove quiet
-__device__ __forceinline__ float min3_raw(float a, float b, float c) {
-  float d;
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// the minimum of a 32x32 accumulator tile's 16 registers (8 instructions)
-__device__ __forceinline__ float tile_min(const f32x16 &a) {
-  const float m0 = min3_raw(a[0], a[1], a[2]), m1 = min3_raw(a[3], a[4], a[5]);
-  const float m2 = min3_raw(a[6], a[7], a[8]), m3 = min3_raw(a[9], a[10], a[11]);
-  const float m4 = min3_raw(a[12], a[13], a[14]);
-  return min3_raw(min3_raw(m0, m1, m2), min3_raw(m3, m4, a[15]), m0);
-}
 // registers r0 .. r0+7 of an accumulator tile (an 8-row sub-block): the smallest value with its row in the 3 low
 // mantissa bits (|packed - m| < 2^-20 |m|) and the second smallest — 3 instructions per element
 __device__ __forceinline__ float2 tile_min8_idx(const f32x16 &a, int r0) {
@@ -288,15 +313,6 @@ __device__ __forceinline__ float2 tile_min8_idx(const f32x16 &a, int r0) {
   }
   return make_float2(b1, b2);
 }
-// v into the sorted four smallest T0 <= T1 <= T2 <= T3 (v_med3_f32 takes its operands as they are)
-#define VI_TOP4(v)                             \
-  {                                            \
-    T3 = __builtin_amdgcn_fmed3f(T2, T3, v);   \
-    T2 = __builtin_amdgcn_fmed3f(T1, T2, v);   \
-    T1 = __builtin_amdgcn_fmed3f(T0, T1, v);   \
-    T0 = min3_raw(T0, v, v);                   \
-  }
-
 // one block image -> LDS: all of it, or (RANK 2) only its hi planes: pieces (chunk c, plane 0, half h) = 4c + h
 template <int NG, int RANK, int NBUF, int WAVES>
 __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, const float *xn, int wave, int lane) {
@@ -316,7 +332,7 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
   }
 }
 
-__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out);
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo);
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
@@ -414,11 +430,11 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
     }
   } else if (a.qimg) {
     // the batch's queries were split once (every query sits in n_probe work items): 16-byte pieces, no arithmetic here
-    const uint4 *qi = a.qimg + (size_t)qid * (NG / 2) * 4 + h;
+    const uint4 *qi = a.qimg + (size_t)qid * (NG / 2) * 4 + h;  // [plane][chunk][half]
 #pragma unroll
     for (int c = 0; c < NG / 2; ++c) {
       uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
-      if (qlive) { hi = qi[c * 4]; lo = qi[c * 4 + 2]; }
+      if (qlive) { hi = qi[c * 2]; lo = qi[NG + c * 2]; }
       qf[2 * c] = __builtin_bit_cast(float4, hi);
       qf[2 * c + 1] = __builtin_bit_cast(float4, lo);
     }
@@ -641,8 +657,10 @@ struct WideArgs {
   float4 *brec;
 };
 
-// -2 q split hi / lo, query-major: piece (chunk c, plane p, half h) of query q at (q * nc + c) * 4 + 2p + h
-__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out) {
+// -2 q split hi / lo, query-major, hi plane first: piece (plane p, chunk c, half h) of query q at q * 4 nc + p * 2 nc + 2 c + h
+// (a batch of bf16-exact queries is ranked from its hi planes alone: they are whole cache lines of their own)
+// *any_lo is raised when some query has a non-zero lo plane (a batch of bf16-exact queries is ranked without them)
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (query, chunk, half)
   if (t >= (uint64_t)nq * nc * 2) return;
   const uint32_t h = (uint32_t)(t & 1u);
@@ -656,8 +674,10 @@ __global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, 
   if (e + 4 < dim) v1 = *reinterpret_cast<const float4 *>(row + e + 4);
   uint4 hi, lo;
   split8(v0, v1, -2.0f, hi, lo);
-  out[qc * 4 + h] = hi;
-  out[qc * 4 + 2 + h] = lo;
+  out[q * 4 * nc + 2 * c + h] = hi;
+  out[q * 4 * nc + 2 * nc + 2 * c + h] = lo;
+  if (__ballot(((lo.x | lo.y | lo.z | lo.w) & 0x7FFF7FFFu) != 0u) != 0ull && (threadIdx.x & 63u) == 0u)  // (-0 halves are zero too)
+    atomicOr(any_lo, 1ull);
 }
 
 __global__ void __launch_bounds__(256, 1) rank_wide_kernel(WideArgs a) {
@@ -710,7 +730,7 @@ __global__ void __launch_bounds__(256, 1) rank_wide_kernel(WideArgs a) {
       } else {
         const uint32_t r = (uint32_t)pi - 32u, qb = r >> 3, c = (r >> 2) & 1u, piece = r & 3u;
         const uint32_t cc = s * kWideChunks + c;
-        if (cc < nc) glds16_asm(a.qimg + ((size_t)gq[qb] * nc + cc) * 4 + piece, buf + pi * 256);
+        if (cc < nc) glds16_asm(a.qimg + (size_t)gq[qb] * nc * 4 + (piece >> 1) * 2 * nc + cc * 2 + (piece & 1u), buf + pi * 256);
       }
     }
   };
@@ -805,6 +825,7 @@ struct SelectCommon {
   uint32_t gq;  // queries per rank work item (a record tile holds 2 * gq pair records)
   unsigned long long *dbg;  // [6] exact re-evaluations, [7] groups whose pair records were read, [8..] see select_body
   uint32_t image_order;     // the rank kernel multiplied the permuted bf16 image (subblock_vector)
+  uint32_t wave_order;      // pair records in the streaming kernel's wave order (scan.hpp: seg_records), else pair order
   uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
 };
 
@@ -966,8 +987,11 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       const uint32_t boff = (uint32_t)__shfl((int)pr.boff, (int)rr);
       const uint32_t nblk = (ln + kWave - 1) / kWave;
       const uint32_t bs = sg * segb, be = min(nblk, bs + segb);
-      const uint32_t npairs = (mine && be > bs) ? (be - bs + 1u) / 2u : 0u;
-      uint32_t mx = npairs;  // wave maximum: segments of very long lists hold more than 16 pairs
+      // records of the segment: pair order (record p = blocks 2p, 2p + 1; component j = sub-block 4p + j), or the streaming
+      // kernel's wave order (record p, component j = 32-vector tile 16 (p >> 2) + 4 j + (p & 3))
+      const uint32_t ntile = be > bs ? 2u * (be - bs) : 0u;
+      const uint32_t npairs = !mine ? 0u : (c.wave_order ? 4u * ((ntile + 15u) / 16u) : (ntile + 3u) / 4u);
+      uint32_t mx = npairs;  // wave maximum: segments of very long lists hold more than 16 records
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
       for (uint32_t p0 = 0; p0 < mx; p0 += 16u) {
@@ -975,17 +999,13 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
         const bool live = p < npairs;
         float4 B = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
         if (live) B = c.brec[(size_t)boff + 2u * c.gq * (sg * seg_records(segb) + p) + c.gq * h2];
-        if (mode == 0) {
-          s1 = offer_bulk_fn(s1, B.x, live ? 0u : kNoPos, (int)K);
-          s1 = offer_bulk_fn(s1, B.y, live ? 1u : kNoPos, (int)K);
-          s1 = offer_bulk_fn(s1, B.z, live ? 2u : kNoPos, (int)K);
-          s1 = offer_bulk_fn(s1, B.w, live ? 3u : kNoPos, (int)K);
-        } else {
-          const float bv[4] = {B.x, B.y, B.z, B.w};
-          const uint32_t blk0 = bs + 2u * p;
+        const float bv[4] = {B.x, B.y, B.z, B.w};
 #pragma unroll
-          for (uint32_t j = 0; j < 4; ++j)  // (!(v > thr): a NaN minimum is expanded, never skipped)
-            push_sub(live && blk0 + (j >> 1) < be && !(bv[j] > thr), rr, (blk0 + (j >> 1)) * 2u + (j & 1u), h2);
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t tl = c.wave_order ? 16u * (p >> 2) + 4u * j + (p & 3u) : 4u * p + j;  // tile of the segment
+          const bool ok = live && tl < ntile;  // (a record's unused components, and records no wave wrote, are not read as values)
+          if (mode == 0) s1 = offer_bulk_fn(s1, ok ? bv[j] : INFINITY, ok ? j : kNoPos, (int)K);
+          else push_sub(ok && !(bv[j] > thr), rr, 2u * bs + tl, h2);  // (!(v > thr): a NaN minimum is expanded, never skipped)
         }
       }
     }
@@ -1435,7 +1455,7 @@ bool hi_only_ok() {
   return !(e && *e == '0');
 }
 
-SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2, uint32_t gq) {
+SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2, uint32_t gq, bool wave_order = false) {
   const double u = 1.01 * std::ldexp(1.0, -24);
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
@@ -1451,6 +1471,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.xmax2 = xmax2;
   c.gq = gq;
   c.image_order = rank_bf16() ? 1u : 0u;
+  c.wave_order = wave_order ? 1u : 0u;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.cur().ws.stats.p : nullptr;
@@ -1461,6 +1482,13 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
 uint32_t env_xmode() {
   const char *xm = getenv("VI_FILTER_XMODE");
   return xm ? (uint32_t)atoi(xm) : 0u;
+}
+
+// items of one tile stream dealt to the same XCD in a row (item_desc_kernel); VI_ITEM_RUN=1: plain round-robin
+uint32_t item_run() {
+  const char *e = getenv("VI_ITEM_RUN");
+  const int v = e ? atoi(e) : 8;
+  return (uint32_t)std::min(std::max(v, 1), 256);
 }
 
 }  // namespace
@@ -1640,9 +1668,14 @@ static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint6
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t nc = ix.dq / 4;
   VI_TRY(ws.qimg.reserve((uint64_t)nq * nc * 4 * 4));  // uint32 words: 4 pieces of 16 B per (query, chunk)
+  if (!ws.stats_zeroed) {  // [13]: some query has a lo plane (read back with the grouping's counts); [14]: the rank kernel's
+    VI_TRY(ws.stats.reserve(16));  // work counter — both reset by item_cols_kernel after their use
+    VI_HIP(hipMemsetAsync(ws.stats.p, 0, 16 * sizeof(uint64_t), st));
+    ws.stats_zeroed = true;
+  }
   const uint64_t nt = (uint64_t)nq * nc * 2;
   hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
-                     (uint4 *)ws.qimg.p);
+                     (uint4 *)ws.qimg.p, (unsigned long long *)(ws.stats.p + 13));
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -1689,7 +1722,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[1], st));
   // ---- 2. group all (query, probe) pairs by list ----
-  uint64_t hstats[13];
+  uint64_t hstats[14];
   // queries per rank work item: 128 when lists are shared by many queries of the batch, 32 when a list is probed by a
   // handful (large balanced indexes): a 128-query group would keep three of its four waves idle
   // The choice needs the batch's histogram, which only the grouping produces: the first batch of a shape (nq, P) goes by
@@ -1703,6 +1736,16 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     if (h.nq == nq && h.P == P) gq = h.gq;
   if (gqe) gq = atoi(gqe) == 32 ? 32u : 128u;
   if (ix.dim > kNarrowDim) gq = 128u;  // the wide kernel's C tile holds 128 queries
+  // D <= 128 with bf16 ranking: the streaming kernel (rank_stream.hip); a work item holds up to 128 queries and costs
+  // MFMAs for its live 32-query tiles only, so there is no group size to choose.  VI_RANK_STREAM=0: block-synchronous kernel
+  const bool stream = ix.dim <= kNarrowDim && rank_bf16() && !(getenv("VI_RANK_STREAM") && *getenv("VI_RANK_STREAM") == '0');
+  if (stream) {
+    // groups of 256 queries when the ranking needs hi planes only on both sides (bf16-exact data, and the previous
+    // batch's queries were bf16-exact too: this batch's are known only after the grouping); VI_STREAM_GQ forces
+    const char *e = getenv("VI_STREAM_GQ");
+    gq = ix.lists_lo_zero && hi_only_ok() && ws.queries_hi_only ? 256u : 128u;
+    if (e) gq = atoi(e) == 256 ? 256u : 128u;
+  }
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
   {
     const double fill128 = hstats[12] ? (double)hstats[0] / ((double)hstats[12] * 128.0 * 64.0) : 0.0;
@@ -1715,6 +1758,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       ws.gq_hint.push_back({nq, P, next});
     }
   }
+  ws.queries_hi_only = hstats[13] == 0;
   stt.scanned_vectors = hstats[0];
   stt.scan_items = hstats[1];
   stt.filter_tile_blocks = hstats[3];
@@ -1746,36 +1790,75 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     stt.rank_mode = 2;
     stt.group_queries = gq;
   } else {
-    FilterArgs a{};
-    a.blocks = rank_bf16() ? (const float4 *)ix.lists_bf16.p : (const float4 *)ix.lists.blocks.p;
-    a.xnorm = rank_bf16() ? ix.xnorm_img.p : ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
-    a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
-    a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
-    a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
-    a.tile_start = ws.tile_start.p;
     const uint32_t nitems = (uint32_t)hstats[1];
-    VI_TRY(ws.item_list.reserve(std::max<uint32_t>(1, nitems)));
     VI_TRY(ws.items.reserve(std::max<uint32_t>(1, nitems) * 8ull));
     if (nitems) {
       hipLaunchKernelGGL(item_desc_kernel, dim3((nitems + 255) / 256), dim3(256), 0, st, ws.item_start.p, ws.seg_start.p,
                          ix.list_len.p, ix.list_first_block.p, ws.tile_start.p, (uint32_t)nlists, nitems, segb0, gq,
-                         (uint4 *)ws.items.p);
+                         item_run(), (uint4 *)ws.items.p);
       VI_HIP(hipGetLastError());
     }
-    a.item_list = nullptr;
-    a.items = (const uint4 *)ws.items.p;
-    a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
-    a.xmode = env_xmode();
-    a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
     const int rank_mode = rank_bf16() ? (ix.lists_lo_zero && hi_only_ok() ? 2 : 1) : 0;
     stt.rank_mode = (uint64_t)rank_mode + 1;
     stt.group_queries = gq;
-    VI_TRY(launch_filter(a, dq, (uint32_t)hstats[1], rank_mode, gq, st));
+    if (stream) {
+      // queries in LDS, vectors through registers, no barrier in the block loop, persistent workgroups (rank_stream.hip)
+      VI_TRY(ws.item_qcol.reserve(std::max<uint64_t>(1, (uint64_t)nitems * gq)));
+      VI_TRY(ws.item_grec.reserve(std::max<uint64_t>(1, (uint64_t)nitems * gq)));
+      VI_TRY(ws.item_sdesc.reserve(std::max<uint64_t>(1, (uint64_t)nitems * 4)));
+      if (nitems) {
+        hipLaunchKernelGGL(item_cols_kernel, dim3(nitems), dim3(128), 0, st, (const uint4 *)ws.items.p, ws.pairs.p, ws.qoff.p,
+                           ws.pair_rel.p, P, gq, ws.item_qcol.p, ws.item_grec.p, (uint4 *)ws.item_sdesc.p, ws.gpos.p, ws.stats.p);
+        VI_HIP(hipGetLastError());
+      }
+      RankStreamArgs a{(const uint4 *)ix.lists_bf16.p, ix.xnorm_img.p, (const uint4 *)ws.qimg.p, (const uint4 *)ws.item_sdesc.p, nitems,
+                       ws.item_qcol.p, ws.item_grec.p, (uint32_t *)(ws.stats.p + 14), (float4 *)ws.gval.p,
+                       (float4 *)ws.brec.p, nullptr, env_xmode()};
+      const bool qlo = hstats[13] != 0 || !hi_only_ok();
+      const bool prof = getenv("VI_STREAM_PROF") != nullptr;
+      if (prof) {
+        VI_TRY(ws.prof.reserve(24));
+        VI_HIP(hipMemsetAsync(ws.prof.p, 0, 24 * sizeof(uint64_t), st));
+        VI_HIP(hipMemsetAsync(ws.prof.p + 16, 0xFF, sizeof(uint64_t), st));
+        a.prof = (unsigned long long *)ws.prof.p;
+      }
+      VI_TRY(launch_rank_stream(a, dq / 4, nitems, rank_mode, qlo || rank_mode == 1, gq, st));
+      if (prof) {
+        uint64_t h[24];
+        VI_HIP(hipMemcpyAsync(h, ws.prof.p, sizeof(h), hipMemcpyDeviceToHost, st));
+        VI_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "rank_stream wave-0 ticks (100 MHz) summed over workgroups: multiply %llu (of which waiting for tiles %llu) "
+                "end-of-item wait %llu gather %llu merge %llu | items %llu steps %llu | loop total %llu\n",
+                (unsigned long long)h[0], (unsigned long long)h[6], (unsigned long long)h[1], (unsigned long long)h[2],
+                (unsigned long long)h[3], (unsigned long long)h[4], (unsigned long long)h[5], (unsigned long long)h[7]);
+        fprintf(stderr, "   loops entered over %llu ticks, last exit %llu ticks after the first entry\n", (unsigned long long)(h[17] - h[16]),
+                (unsigned long long)(h[18] - h[16]));
+        fprintf(stderr, "   longest workgroup loop %llu ticks, workgroups with items %llu, most items in one %llu\n", (unsigned long long)h[13],
+                (unsigned long long)h[14], (unsigned long long)h[15]);
+        fprintf(stderr, "   after B1: T+idx %llu, DMA issue %llu, vmcnt(0) %llu, B2 %llu | after B2: merge+stores %llu, idx read %llu, load_item %llu\n",
+                (unsigned long long)h[8], (unsigned long long)h[9], (unsigned long long)h[10], (unsigned long long)h[2],
+                (unsigned long long)h[11], (unsigned long long)h[12], (unsigned long long)h[3]);
+      }
+    } else {
+      FilterArgs a{};
+      a.blocks = rank_bf16() ? (const float4 *)ix.lists_bf16.p : (const float4 *)ix.lists.blocks.p;
+      a.xnorm = rank_bf16() ? ix.xnorm_img.p : ix.xnorm.p; a.dq = dq; a.dim = ix.dim; a.Q = Qd;
+      a.first_block = ix.list_first_block.p; a.list_len = ix.list_len.p; a.item_start = ws.item_start.p;
+      a.seg_start = ws.seg_start.p; a.pairs = ws.pairs.p; a.nlists = (uint32_t)nlists; a.P = P; a.segb0 = segb0;
+      a.qoff = ws.qoff.p; a.rel = ws.pair_rel.p; a.rec_stride = 0;
+      a.tile_start = ws.tile_start.p;
+      a.item_list = nullptr;
+      a.items = (const uint4 *)ws.items.p;
+      a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
+      a.xmode = env_xmode();
+      a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
+      VI_TRY(launch_filter(a, dq, nitems, rank_mode, gq, st));
+    }
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
   // ---- 4. select ----
   {
-    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2, gq), (uint32_t)nq, P, (uint32_t)k, segb0,
+    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2, gq, stream), (uint32_t)nq, P, (uint32_t)k, segb0,
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }

@@ -195,7 +195,7 @@ vi_status sort_rows_u64(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream
 
 // declared in search_kernels.hip
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[13], hipStream_t st, bool histogram_done);
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done);
 
 vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
                                       float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
@@ -273,7 +273,7 @@ vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, ui
     VI_HIP(hipMemsetAsync(ws.sort_keys.p, 0xFF, m * L * sizeof(uint64_t), st));
     const double avg_q_per_list = (double)m * P / (double)std::max<uint64_t>(1, nlists);
     const int qg = pick_qg(dq, avg_q_per_list, ix.order);
-    uint64_t hstats[13];
+    uint64_t hstats[14];
     VI_TRY(launch_grouping(ix, ws.probes.p + q0 * P, m, P, qg, segb0, hstats, st, false));
     stt.scan_items += hstats[1];
     ScanArgs a{};

@@ -4,12 +4,52 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 namespace vi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// minimum of three without the canonicalising v_max the compiler puts in front of fminf on values it cannot prove quiet
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+  float d;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// the minimum of a 32x32 accumulator tile's 16 registers (12 instructions).  The accumulator registers themselves are
+// read by compiler-visible instructions only — v_med3_f32(-inf, x, y) = min(x, y), operands taken as they are: the
+// hazard recogniser does not look into inline asm, and an asm v_min3_f32 placed right behind the last MFMA of a chain
+// read the accumulator before the matrix pipe had written it (found with the streaming kernel: missed neighbours).
+// The -inf comes out of an asm so that the compiler cannot fold the median into canonicalize + v_min (3 instructions).
+__device__ __forceinline__ float opaque_neg_inf() {
+  float v;
+  asm("v_mov_b32 %0, 0xff800000" : "=v"(v));
+  return v;
+}
+__device__ __forceinline__ void tile_min_level1(const f32x16 &a, float ninf, float (&p)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_fmed3f(ninf, a[2 * i], a[2 * i + 1]);
+}
+__device__ __forceinline__ float tile_min_level2(const float (&p)[8]) {
+  const float m0 = min3_raw(p[0], p[1], p[2]), m1 = min3_raw(p[3], p[4], p[5]), m2 = min3_raw(p[6], p[7], p[7]);
+  return min3_raw(m0, m1, m2);
+}
+__device__ __forceinline__ float tile_min(const f32x16 &a) {
+  float p[8];
+  tile_min_level1(a, opaque_neg_inf(), p);
+  return tile_min_level2(p);
+}
+// v into the sorted four smallest T0 <= T1 <= T2 <= T3 (v_med3_f32 takes its operands as they are)
+#define VI_TOP4(v)                             \
+  {                                            \
+    T3 = __builtin_amdgcn_fmed3f(T2, T3, v);   \
+    T2 = __builtin_amdgcn_fmed3f(T1, T2, v);   \
+    T1 = __builtin_amdgcn_fmed3f(T0, T1, v);   \
+    T0 = min3_raw(T0, v, v);                   \
+  }
 
 __device__ __forceinline__ uint32_t bf16_rn(float x) {  // round-to-nearest-even, finite inputs
   const uint32_t b = __float_as_uint(x);
@@ -50,6 +90,13 @@ __device__ __forceinline__ void tile_dma_image(float *tile, const float4 *src, c
 __device__ __forceinline__ void glds16_asm(const void *gsrc, float *lds_dst) {
   unsigned keep;
   const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// ... with the destination given as a (wave-uniform) LDS byte address: no generic -> LDS pointer conversion per call
+__device__ __forceinline__ void glds16_at(const void *gsrc, unsigned lds_addr) {
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }

@@ -61,6 +61,12 @@ __host__ __device__ inline uint32_t list_segments(uint32_t len, uint32_t segb0, 
   return nblk == 0 ? 0u : (nblk + sb - 1) / sb;
 }
 
+// pair records one list segment of segb blocks reserves per query group (every segment of a list reserves the same
+// number): a record holds four sub-block minima.  The streaming rank kernel fills them wave by wave — record
+// (i >> 2) * 4 + w, component i & 3 = 32-vector tile 4 i + w of the segment — the block-synchronous kernels in pair order
+// (record p = blocks 2p, 2p + 1); 4 * ceil(segb / 8) covers both.
+__host__ __device__ inline uint32_t seg_records(uint32_t segb) { return 4u * ((segb + 7u) / 8u); }
+
 // query-group width for a unit (table or list) probed by `avg_queries_per_unit` queries
 int pick_qg(uint32_t dq, double avg_queries_per_unit, int order);
 vi_status launch_scan(const ScanArgs &a, int qg, int order, bool coarse, uint32_t nitems_upper, hipStream_t st);

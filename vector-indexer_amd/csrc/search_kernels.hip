@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     vec += (unsigned long long)c * len;
     mtile += (unsigned long long)chunks * ((len + 63) / 64);  // (query group, block) tiles ranked on the matrix cores
     mtile128 += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);  // ... if the groups held 128 queries
-    tile += chunks * ns * ((segb + 1) / 2);  // record tiles: one per (query group, 2 blocks of a segment); count checked on the host
+    tile += chunks * ns * seg_records(segb);  // record tiles of the MFMA engine (scan.hpp); count checked on the host
     rec += 2ull * c * ns;
   }
   // inclusive scans across the wave, then across the 16 waves
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     if (tile_start) tile_start[l] = rt;
     const uint32_t c = cnt[l];
     rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += ((c + qg - 1) / qg) * ns * ((segb + 1) / 2);
+    rt += ((c + qg - 1) / qg) * ns * seg_records(segb);
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
@@ -1375,7 +1375,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 // Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[13], hipStream_t st, bool histogram_done) {
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1396,7 +1396,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   }
   VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st));
   // the host waits for the counts (grid size, scratch) while the scatter runs
-  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 14 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.cur().ev[5], st));
   hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                      (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
