@@ -70,6 +70,13 @@ SETTINGS = [
     ("gq256 x16", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 16}),
     ("gq256 segb 16", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 16}),
     ("gq256 segb 64", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 64}),
+    ("s x1 tiles not re-read", {"VI_FILTER_XMODE": 1}),
+    ("s x2 no epilogue", {"VI_FILTER_XMODE": 2}),
+    ("s x3", {"VI_FILTER_XMODE": 3}),
+    ("s x8 no record store", {"VI_FILTER_XMODE": 8}),
+    ("s x16 no multiply", {"VI_FILTER_XMODE": 16}),
+    ("s x32 no gather", {"VI_FILTER_XMODE": 32}),
+    ("s x43", {"VI_FILTER_XMODE": 43}),
     ("gq256 segb 128", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 128}),
     ("gq128 segb 64", {"VI_STREAM_GQ": 128, "VI_FILTER_SEGB": 64}),
     ("gq128 segb 128", {"VI_STREAM_GQ": 128, "VI_FILTER_SEGB": 128}),
@@ -94,6 +101,10 @@ SETTINGS = [
 if os.environ.get("SET"):  # SET=a,b,c: only these settings (prefix match)
     want = os.environ["SET"].split(",")
     SETTINGS = [s for s in SETTINGS if any(s[0].startswith(w) for w in want)]
+if os.environ.get("AB"):  # AB=a,b: alternate two settings three times (same process, same box)
+    names = os.environ["AB"].split(",")
+    ab = [s for s in SETTINGS if s[0] in names]
+    SETTINGS = ab * 3
 only = os.environ.get("EXP")
 probes = [int(a) for a in sys.argv[1:]] or [16, 32]
 for p in probes:

@@ -88,3 +88,73 @@ def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
         if k["nbuf"] == 3:  # ring of three: the wait also leaves this iteration's LDS-DMA (<= 5 per wave) in flight
             allowed = {str(i) for i in range(8)}
         assert "1" in waits and set(waits) <= allowed, f"{name}: vmcnt waits {waits}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# streaming rank kernel (rank_stream.hip): the default instantiations (groups of 128 queries) must not spill, and a
+# step of the tile loop must multiply WITHOUT waiting for the tile it has just requested: the compiler once placed
+# `s_waitcnt vmcnt(0)` in front of the first MFMA of every step (after the prefetch of the next tile), which the
+# explicit tile_landed() touch moved in front of the prefetch.
+# ---------------------------------------------------------------------------------------------------------------
+STREAM_SRC = os.path.join(ROOT, "vector-indexer_amd", "csrc", "rank_stream.hip")
+
+
+@pytest.fixture(scope="module")
+def stream_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("isa") / "rank_stream.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"]
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", out, STREAM_SRC], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def stream_kernels(asm_text):
+    out = {}
+    for m in re.finditer(r"^(_ZN2vi12_GLOBAL__N_118rank_stream_kernelILi(\d+)ELi(\d)ELb([01])ELi(\d)EEEvNS_14RankStreamArgsE):[^\n]*\n(.*?)\n\.Lfunc_end",
+                         asm_text, re.S | re.M):
+        name, nc, rank, qlo, nu, body = m.groups()
+        meta = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(.*?)\.end_amdhsa_kernel", asm_text, re.S).group(1)
+        out[name] = dict(body=body, meta=meta, nc=int(nc), rank=int(rank), qlo=qlo == "1", nu=int(nu))
+    return out
+
+
+def test_streaming_rank_kernels_do_not_spill(stream_asm):
+    ks = stream_kernels(stream_asm)
+    assert len(ks) == 32   # NC 1..8 x {queries hi-only, hi + lo} x {groups of 128, 256}
+    for name, k in ks.items():
+        if k["nu"] != 4:
+            continue   # groups of 256 are an experiment knob (VI_STREAM_GQ=256); its hi + lo fallback does spill
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", k["meta"]).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
+        assert not re.search(r"\bscratch_(load|store)|buffer_(load|store)", k["body"]), name
+
+
+def test_streaming_rank_kernel_multiplies_while_the_next_tile_loads(stream_asm):
+    ks = stream_kernels(stream_asm)
+    checked = 0
+    for name, k in ks.items():
+        if k["nu"] != 4 or k["nc"] < 4:
+            continue
+        lines = k["body"].split("\n")
+        tile_loads = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l]
+        mfmas = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+        # every run of tile loads that is followed by a step's MFMAs: no vmcnt wait between its last load and the step's last MFMA
+        steps = 0
+        for i in tile_loads:
+            nxt = [m for m in mfmas if m > i]
+            if not nxt or any(i < t < nxt[0] for t in tile_loads):
+                continue   # not the last load of its run
+            chain = [m for m in nxt if m < i + 600][: k["nc"] * (2 if k["qlo"] else 1) * 4]
+            if len(chain) < k["nc"]:
+                continue
+            between = "\n".join(lines[i + 1:chain[-1]])
+            if "s_barrier" in between:
+                continue   # (the run in front of the item loop)
+            # (counted waits of the conditional last-step block in between — the next item's first tile goes into registers
+            # whose previous loads the compiler cannot prove complete — are harmless; a full drain is the bug)
+            assert not re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", between), f"{name}: a step drains vector memory after its prefetch"
+            steps += 1
+        assert steps >= 2, name   # the two halves of the unrolled tile loop
+        checked += 1
+    assert checked >= 8

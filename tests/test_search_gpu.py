@@ -494,3 +494,28 @@ def test_wide_vectors_run_on_the_mfma_engine(d, n, nlist, tmp_path):
         if os.environ.get("VI_FILTER") != "0" and os.environ.get("VI_FILTER_BF16") != "0":
             assert gpu.last_stats()["rank_mode"] == 2, (k, n_probe)
     check_parity(orc, gpu, Q[:5], 10, 4)
+
+
+@pytest.mark.parametrize("n,d,nq,k,P", [(200, 8, 1, 1, 50), (3000, 8, 5, 3, 8), (3000, 32, 40, 10, 8), (20000, 128, 300, 10, 16),
+                                        (20000, 64, 700, 10, 16), (12000, 96, 260, 64, 32), (9000, 48, 129, 5, 4)])
+@pytest.mark.parametrize("variant", ["stream-128", "stream-256", "block-synchronous"])
+def test_streaming_rank_kernel_parity(n, d, nq, k, P, variant, tmp_path, monkeypatch):
+    """bf16-exact (8-bit valued) data takes the streaming rank kernel (rank_stream.hip): groups of 128 queries with two
+    query images, groups of 256 (an experiment knob; the first batch of a shape still runs 128), and the
+    block-synchronous kernel it replaced — all three against the oracle, ids and distance bits; integer and
+    non-integer queries (the latter need the queries' lo plane), two batches per index (the second reuses the
+    workspace and, with VI_STREAM_GQ=256, switches the group size)."""
+    if os.environ.get("VI_FILTER") == "0" or os.environ.get("VI_FILTER_BF16") == "0":
+        pytest.skip("the streaming kernel belongs to the bf16 MFMA engine")
+    monkeypatch.setenv("VI_RANK_STREAM", "0" if variant == "block-synchronous" else "1")
+    monkeypatch.setenv("VI_STREAM_GQ", "256" if variant == "stream-256" else "128")
+    rng = np.random.default_rng(n + d)
+    X = rng.integers(0, 200, size=(n, d)).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X)
+    Qi = np.ascontiguousarray(X[rng.integers(0, n, nq)] + rng.integers(-3, 4, size=(nq, d)), dtype=np.float32)
+    Qf = np.ascontiguousarray(Qi + rng.random((nq, d), dtype=np.float32) * 0.37, dtype=np.float32)
+    for Q in (Qi, Qi[::-1].copy(), Qf):
+        check_parity(orc, gpu, Q, k, P)
+        st = gpu.last_stats()
+        if os.environ.get("VI_FILTER_HI_ONLY") != "0":
+            assert st["rank_mode"] == 3   # hi planes only

@@ -1736,15 +1736,15 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     if (h.nq == nq && h.P == P) gq = h.gq;
   if (gqe) gq = atoi(gqe) == 32 ? 32u : 128u;
   if (ix.dim > kNarrowDim) gq = 128u;  // the wide kernel's C tile holds 128 queries
-  // D <= 128 with bf16 ranking: the streaming kernel (rank_stream.hip); a work item holds up to 128 queries and costs
-  // MFMAs for its live 32-query tiles only, so there is no group size to choose.  VI_RANK_STREAM=0: block-synchronous kernel
-  const bool stream = ix.dim <= kNarrowDim && rank_bf16() && !(getenv("VI_RANK_STREAM") && *getenv("VI_RANK_STREAM") == '0');
+  // D <= 128, stored values bf16-exact (hi planes only): the streaming kernel (rank_stream.hip).  A work item holds up to
+  // 128 queries and costs MFMAs for its live 32-query tiles only, so there is no group size to choose (VI_STREAM_GQ=256:
+  // groups of 256 when the queries are bf16-exact too — measured equal).  VI_RANK_STREAM=0: block-synchronous kernel.
+  // (bf16 x 3 keeps the block-synchronous kernel: two tiles of hi + lo planes do not fit in the streaming kernel's registers)
+  const bool stream = ix.dim <= kNarrowDim && rank_bf16() && ix.lists_lo_zero && hi_only_ok() &&
+                      !(getenv("VI_RANK_STREAM") && *getenv("VI_RANK_STREAM") == '0');
   if (stream) {
-    // groups of 256 queries when the ranking needs hi planes only on both sides (bf16-exact data, and the previous
-    // batch's queries were bf16-exact too: this batch's are known only after the grouping); VI_STREAM_GQ forces
     const char *e = getenv("VI_STREAM_GQ");
-    gq = ix.lists_lo_zero && hi_only_ok() && ws.queries_hi_only ? 256u : 128u;
-    if (e) gq = atoi(e) == 256 ? 256u : 128u;
+    gq = e && atoi(e) == 256 && ws.queries_hi_only ? 256u : 128u;
   }
   VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
   {
@@ -1817,8 +1817,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       const bool qlo = hstats[13] != 0 || !hi_only_ok();
       const bool prof = getenv("VI_STREAM_PROF") != nullptr;
       if (prof) {
-        VI_TRY(ws.prof.reserve(24));
-        VI_HIP(hipMemsetAsync(ws.prof.p, 0, 24 * sizeof(uint64_t), st));
+        VI_TRY(ws.prof.reserve(32 + 4 * 1024));
+        VI_HIP(hipMemsetAsync(ws.prof.p, 0, (32 + 4 * 1024) * sizeof(uint64_t), st));
         VI_HIP(hipMemsetAsync(ws.prof.p + 16, 0xFF, sizeof(uint64_t), st));
         a.prof = (unsigned long long *)ws.prof.p;
       }
@@ -1831,6 +1831,18 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                 "end-of-item wait %llu gather %llu merge %llu | items %llu steps %llu | loop total %llu\n",
                 (unsigned long long)h[0], (unsigned long long)h[6], (unsigned long long)h[1], (unsigned long long)h[2],
                 (unsigned long long)h[3], (unsigned long long)h[4], (unsigned long long)h[5], (unsigned long long)h[7]);
+        if (const char *dump = getenv("VI_STREAM_PROF_DUMP")) {
+          std::vector<uint64_t> w(4 * 1024);
+          VI_HIP(hipMemcpy(w.data(), ws.prof.p + 32, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+          if (FILE *f = fopen(dump, "w")) {
+            uint64_t base = ~0ull;
+            for (int i = 0; i < 1024; ++i) if (w[4 * i + 1]) base = std::min(base, w[4 * i]);
+            for (int i = 0; i < 1024; ++i)  // workgroup, start, end (10 ns ticks after the first start), items
+              if (w[4 * i + 1]) fprintf(f, "%d %llu %llu %llu\n", i, (unsigned long long)(w[4 * i] - base), (unsigned long long)(w[4 * i + 1] - base),
+                                        (unsigned long long)w[4 * i + 2]);
+            fclose(f);
+          }
+        }
         fprintf(stderr, "   loops entered over %llu ticks, last exit %llu ticks after the first entry\n", (unsigned long long)(h[17] - h[16]),
                 (unsigned long long)(h[18] - h[16]));
         fprintf(stderr, "   longest workgroup loop %llu ticks, workgroups with items %llu, most items in one %llu\n", (unsigned long long)h[13],

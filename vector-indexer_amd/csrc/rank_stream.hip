@@ -105,6 +105,35 @@ __device__ __forceinline__ void tile_landed(const TileRegs<NC, NA> &t) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 8 (the instruction takes an immediate; a stricter wait is always safe)
+__device__ __forceinline__ void wait_vmcnt(uint32_t n) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// returning atomic increment whose result the CALLER waits for (s_waitcnt vmcnt) before using it
+__device__ __forceinline__ uint32_t queue_pop_asm(uint32_t *counter) {
+  uint32_t ret;
+  const uint32_t one = 1u;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(counter), "v"(one) : "memory");
+  return ret;
+}
+
+// the same for the next item's description: placed right behind a tile's wait (its loads are older than the tile's)
+__device__ __forceinline__ void item_landed(const ItemRaw &r) {
+  asm volatile("" ::"v"(r.d.x), "v"(r.d.y), "v"(r.d.z), "v"(r.d.w), "v"(r.qid), "v"(r.rec[0]), "v"(r.rec[1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // RANK 1: bf16 x 3 (vector hi + lo planes, query hi + lo).  RANK 2: the stored vectors are bf16-exact (hi plane only);
 // QLO says whether the batch's queries need their lo plane (false: every -2 q is bf16-exact too — 8-bit descriptors).
 // NU = 32-query tiles per work item (4: groups of 128 queries; 8: groups of 256 — half the tile loads per query and
@@ -177,6 +206,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     }
   };
 
+  const unsigned long long rt_begin = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;  // (100 MHz, chip-wide)
   // ---- pipeline fill: two item indices, their descriptions, the first item's queries and first tile.  A workgroup holds
   //      its current item and the next; the one after is claimed during the current item's last step — items claimed
   //      early cannot be taken by a workgroup that runs dry, and the launch ends with its slowest workgroup ----
@@ -196,6 +226,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
   gather(0u, ic.nqi, rc.qid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the LDS-DMA is invisible to the compiler's counters)
   __syncthreads();
+  tile_landed<NC, NA>(ta);
 
   // diagnostic (-DVI_STREAM_PROF_BUILD, a.prof != null): s_memtime ticks wave 0 of this workgroup spent in [0] multiplying,
   // [1] waiting for the other waves at the item's end, [8..10, 2] between the barriers, [11, 12, 3] after them; [4] items
@@ -211,6 +242,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     }
   };
   uint32_t buf = 0;  // image of the current item (DB)
+  uint32_t n_items = 0;
   // piece (plane p, chunk c, half h) of query 32 u + j: (row base | swizzle of the lane) XOR the piece (StreamLayout)
   const uint32_t lane_row = ((uint32_t)j * RP + L::swz(0u, (uint32_t)j)) * 16u;
   while (cur < a.nitems) {
@@ -218,9 +250,14 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     ItemRegs in{0u, 0u, 0u, 0u};
     // the next item's description (requested at the end of the previous item) is decoded, its queries are requested
     // and the item after it is claimed as late as this wave can afford: before its last step
-    auto last_step = [&]() {
+    auto last_step = [&](TileRegs<NC, NA> &spare) {
       in = decode_item(rn);
-      if (threadIdx.x == 0) after = fixed ? nxt + gridDim.x : atomicAdd(a.queue, 1u);
+      // this wave's first tile of the next item, into the tile registers the last step does not use: requested BEFORE the
+      // step's record stores, so that waiting for it (and the queries) at the item's end does not wait for the stores
+      if ((uint32_t)wave < in.ntiles) load_tile<NC, NA>(spare, a.img, a.xnorm, in.blk00 + ((uint32_t)wave >> 1), (uint32_t)wave & 1u, j, h);
+      // (asm: the compiler turns atomicAdd under a one-lane branch into its wave-aggregated form, which waits for the
+      // result — and every older load of the wave — on the spot; the result is needed at the item's end)
+      if (threadIdx.x == 0) after = fixed ? nxt + gridDim.x : queue_pop_asm(a.queue);
       if (DB) gather(buf ^ 1u, in.nqi, rn.qid);
     };
     const uint32_t nqi = ic.nqi, nu = (ic.nqi + 31u) >> 5, ntiles = ic.ntiles, blk00 = ic.blk00;
@@ -306,24 +343,26 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     //      requested right before the wave's last step: their latency runs under that step and the wait for the
     //      other waves ----
     const bool restage = !(a.xmode & 1u);
-    bool prepared = false;
+    bool prepared = false, next_in_tb = false;
     for (uint32_t i = 0;; i += 2) {
       const uint32_t t0 = 4u * i + (uint32_t)wave;
       if (t0 >= ntiles || (a.xmode & 16u)) break;
       const uint32_t t1 = t0 + 4u, t2 = t0 + 8u;
       tile_landed<NC, NA>(ta);
+      item_landed(rn);  // (older than the tile: free)
       if (t1 < ntiles && restage) load_tile<NC, NA>(tb, a.img, a.xnorm, blk00 + (t1 >> 1), t1 & 1u, j, h);
-      if (t1 >= ntiles) { last_step(); prepared = true; }
+      if (t1 >= ntiles) { last_step(tb); prepared = true; next_in_tb = true; }
       step(ta, i, t1 >= ntiles);
       if (t1 >= ntiles) break;
       tile_landed<NC, NA>(tb);
+      item_landed(rn);
       if (t2 < ntiles && restage) load_tile<NC, NA>(ta, a.img, a.xnorm, blk00 + (t2 >> 1), t2 & 1u, j, h);
-      if (t2 >= ntiles) { last_step(); prepared = true; }
+      if (t2 >= ntiles) { last_step(ta); prepared = true; }
       step(tb, i + 1u, t2 >= ntiles);  // (ablation xmode 1: whatever the registers hold)
     }
-    if (!prepared) last_step();  // (a wave without tiles in this item)
-    // this wave's first tile of the next item
-    if ((uint32_t)wave < in.ntiles) load_tile<NC, NA>(ta, a.img, a.xnorm, in.blk00 + ((uint32_t)wave >> 1), (uint32_t)wave & 1u, j, h);
+    if (!prepared) last_step(ta);  // (a wave without tiles in this item)
+    // record stores this wave issued after those requests (its last step's, one per live query tile)
+    const uint32_t young_stores = (ntiles > (uint32_t)wave && !(a.xmode & (8u | 16u))) ? nu : 0u;
 
     // ---- item end.  Group records: their four values are the minima of the four waves' tile classes (tiles = w mod
     //      4 of the segment), sorted: four distinct sub-blocks' minima, the smallest of them the segment's minimum —
@@ -335,14 +374,22 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
 #pragma unroll
     for (int u = 0; u < NU; ++u)
       if ((uint32_t)u < nu) s_T[(wave * NU + u) * kWave + lane] = T[u];
-    if (threadIdx.x == 0) s_idx[0] = after;
     lap(8);
     if (!DB) gather(0u, in.nqi, rn.qid);
     lap(9);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next item's queries (and first tile) have landed
+    // the next item's queries and first tile have landed; with two images they are older than the last step's stores
+    if (DB) wait_vmcnt(young_stores);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) s_idx[0] = after;  // (behind the wait: queue_pop_asm's result has arrived)
     lap(10);
     __syncthreads();
     lap(2);
+    if (next_in_tb) ta = tb;
+    // (nothing of this wave is in flight here: the compiler's wait for rc.rec — it cannot know that — belongs HERE and
+    // not between the two record stores below, where it would wait for the first store to complete)
+    asm volatile("" ::"v"(rc.rec[0]), "v"(rc.rec[1]));
+    tile_landed<NC, NA>(ta);  // (the next item's first tile too: its first step must not wait behind the stores below)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const uint32_t u = (uint32_t)wave + 4u * r;
@@ -364,6 +411,12 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     request_item(nxt, rn);
     lap(3);
     pt[4] += 1;
+    ++n_items;
+  }
+  if (a.prof && threadIdx.x == 0) {  // per workgroup: start, end (100 MHz ticks), items
+    a.prof[32 + 4 * blockIdx.x + 0] = rt_begin;
+    a.prof[32 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    a.prof[32 + 4 * blockIdx.x + 2] = n_items;
   }
   if (prof && lane == 0) {
     pt[7] = __builtin_amdgcn_s_memtime() - tk_begin;
@@ -372,6 +425,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     atomicMax(a.prof + 13, pt[7]);                 // longest loop of a workgroup
     atomicAdd(a.prof + 14, pt[4] ? 1ull : 0ull);   // workgroups that had an item
     atomicMax(a.prof + 15, pt[4]);                 // most items of a workgroup
+    a.prof[32 + 4 * blockIdx.x + 3] = pt[0];
     atomicMin(a.prof + 16, tk_begin);              // first / last workgroup to enter its loop, last to leave (absolute ticks)
     atomicMax(a.prof + 17, tk_begin);
     atomicMax(a.prof + 18, tk_begin + pt[7]);
@@ -406,14 +460,15 @@ vi_status launch_one(const RankStreamArgs &a, uint32_t nitems, hipStream_t st) {
 
 template <int NC>
 vi_status launch_nc(const RankStreamArgs &a, uint32_t nitems, int rank_mode, bool qlo, uint32_t gq, hipStream_t st) {
+  // (bf16 x 3 — RANK 1 — compiles but needs two tiles of hi + lo planes in registers: it spills; the pipeline keeps the
+  // block-synchronous kernel for it and does not instantiate it here)
+  if (rank_mode != 2) return fail(VI_ERR_OTHER, "the streaming rank kernel is built for bf16-exact lists only");
   if (gq == 256) {  // groups of 256 are formed for batches of bf16-exact queries only (filter_search.hip)
-    if (rank_mode == 2 && !qlo) return launch_one<NC, 2, false, 8>(a, nitems, st);
-    if (rank_mode == 2) return launch_one<NC, 2, true, 8>(a, nitems, st);
-    return launch_one<NC, 1, true, 8>(a, nitems, st);
+    if (!qlo) return launch_one<NC, 2, false, 8>(a, nitems, st);
+    return launch_one<NC, 2, true, 8>(a, nitems, st);
   }
-  if (rank_mode == 2 && !qlo) return launch_one<NC, 2, false, 4>(a, nitems, st);
-  if (rank_mode == 2) return launch_one<NC, 2, true, 4>(a, nitems, st);
-  return launch_one<NC, 1, true, 4>(a, nitems, st);
+  if (!qlo) return launch_one<NC, 2, false, 4>(a, nitems, st);
+  return launch_one<NC, 2, true, 4>(a, nitems, st);
 }
 
 }  // namespace
