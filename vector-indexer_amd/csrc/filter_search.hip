@@ -131,6 +131,20 @@ __global__ void image_norms_kernel(const float *xnorm, uint64_t nslots, float *o
   if (s < nslots) out[(s & ~63ull) + image_column((uint32_t)(s & 63u))] = xnorm[s];
 }
 
+// bf16-exact stored values: the hi plane IS the value.  A second copy of it in the blocks' own vector order — piece
+// (chunk c, half h) of vector v at (block * 2 nc + 2c + h) * 64 + v — lets the select re-evaluate a 16-vector sub-block
+// from 256 contiguous bytes per 8 dimensions: half the cache lines of the f32 quads (the MFMA image's column order
+// interleaves the two sub-blocks of a tile within every line).
+__global__ void hi_natural_kernel(const uint4 *img, uint32_t nc, uint64_t nblocks, uint4 *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block, chunk, half, vector)
+  if (t >= nblocks * nc * 2 * 64) return;
+  const uint32_t v = (uint32_t)(t & 63), h = (uint32_t)((t >> 6) & 1);
+  const uint64_t bc = t >> 7;
+  const uint32_t c = (uint32_t)(bc % nc);
+  const uint64_t b = bc / nc;
+  out[((b * nc + c) * 2 + h) * 64 + v] = img[(((b * nc + c) * 4) + h) * 64 + image_column(v)];
+}
+
 // any nonzero lo half in an image? (pieces of 64 uint4: plane = (piece >> 1) & 1)
 __global__ void lo_plane_any_kernel(const uint4 *img, uint64_t npieces, uint32_t *any) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -825,6 +839,7 @@ struct SelectCommon {
   uint32_t gq;  // queries per rank work item (a record tile holds 2 * gq pair records)
   unsigned long long *dbg;  // [6] exact re-evaluations, [7] groups whose pair records were read, [8..] see select_body
   uint32_t image_order;     // the rank kernel multiplied the permuted bf16 image (subblock_vector)
+  const uint4 *hi_nat;      // bf16-exact lists: natural-order hi plane for the exact re-evaluation (hi_natural_kernel), else null
   uint32_t wave_order;      // pair records in the streaming kernel's wave order (scan.hpp: seg_records), else pair order
   uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
 };
@@ -865,6 +880,33 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
   return acc;
 }
 
+// the same sum from the natural-order bf16 hi plane of bf16-exact vectors (hi_natural_kernel): x = bf16 << 16 exactly,
+// so every term and the sequential order are those of exact_pair; 16 bytes carry 8 dimensions
+__device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 *xh, uint32_t dim) {
+  float acc = 0.0f;
+  const uint32_t npiece = (dim + 7u) >> 3;  // (dim % 4 == 0: the last piece may hold 4 dimensions)
+  auto piece = [&](const uint4 &x, uint32_t p) {
+    const float4 q0 = *reinterpret_cast<const float4 *>(qrow + 8 * p);
+    sq_add(acc, q0.x, __uint_as_float(x.x << 16)); sq_add(acc, q0.y, __uint_as_float(x.x & 0xFFFF0000u));
+    sq_add(acc, q0.z, __uint_as_float(x.y << 16)); sq_add(acc, q0.w, __uint_as_float(x.y & 0xFFFF0000u));
+    if (8 * p + 4 < dim) {
+      const float4 q1 = *reinterpret_cast<const float4 *>(qrow + 8 * p + 4);
+      sq_add(acc, q1.x, __uint_as_float(x.z << 16)); sq_add(acc, q1.y, __uint_as_float(x.z & 0xFFFF0000u));
+      sq_add(acc, q1.z, __uint_as_float(x.w << 16)); sq_add(acc, q1.w, __uint_as_float(x.w & 0xFFFF0000u));
+    }
+  };
+  uint32_t p = 0;
+  for (; p + 8 <= npiece; p += 8) {
+    uint4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xh[(size_t)(p + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(x[i], p + i);
+  }
+  for (; p < npiece; ++p) piece(xh[(size_t)p * kWave], p);
+  return acc;
+}
+
 // The select kernels are latency-sensitive code executed once per query; inlining the two heavy pieces at
 // every call site made them ~150 KB each and instruction-fetch bound.  They are real functions with their state
 // passed and returned in registers.
@@ -880,6 +922,15 @@ __device__ __attribute__((noinline)) Top exact_batch_fn(Top sel, const float *qr
                                                         uint32_t key, int K) {
   float d = INFINITY;
   if (live) d = exact_pair(qrow, xv, dim);
+  sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
+}
+
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_bf16_fn(Top sel, const float *qrow, const uint4 *xh, uint32_t dim, bool live,
+                                                             uint32_t key, int K) {
+  float d = INFINITY;
+  if (live) d = exact_pair_bf16(qrow, xh, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
   return sel;
 }
@@ -937,8 +988,12 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     live = live && pos < len && !(c.xmode & 1u);
     n_exact += (uint32_t)__popcll(__ballot(live));
-    sel = exact_batch_fn(sel, qrow, c.blocks + ((size_t)(fb + (live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave),
-                         c.dim, live, (g << kPosBits) | pos, (int)K);
+    if (c.hi_nat)
+      sel = exact_batch_bf16_fn(sel, qrow, c.hi_nat + ((size_t)(fb + (live ? pos : 0u) / kWave) * (c.dq / 2)) * kWave + (pos % kWave),
+                                c.dim, live, (g << kPosBits) | pos, (int)K);
+    else
+      sel = exact_batch_fn(sel, qrow, c.blocks + ((size_t)(fb + (live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave),
+                           c.dim, live, (g << kPosBits) | pos, (int)K);
   };
   // sub-blocks waiting in `pick`: four per round, 16 lanes (= the 16 rows of the sub-block) each
   auto drain_pick = [&]() {
@@ -1472,6 +1527,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.gq = gq;
   c.image_order = rank_bf16() ? 1u : 0u;
   c.wave_order = wave_order ? 1u : 0u;
+  c.hi_nat = nullptr;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.cur().ws.stats.p : nullptr;
@@ -1571,6 +1627,12 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
     VI_HIP(hipStreamSynchronize(ix->stream));
     ix->lists_lo_zero = np_l > 0 && h_any[0] == 0;
     ix->cent_lo_zero = np_c > 0 && h_any[1] == 0;
+    if (ix->lists_lo_zero && ix->dim <= kNarrowDim) {  // exact re-evaluation from bf16 (select_kernel), VI_EXACT_BF16=0: from f32
+      VI_TRY(ix->lists_hi_nat.reserve(ix->lists.nblocks * per_block / 2));
+      hipLaunchKernelGGL(hi_natural_kernel, dim3((uint32_t)((nt_l + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const uint4 *)ix->lists_bf16.p, ix->dq / 4, ix->lists.nblocks, (uint4 *)ix->lists_hi_nat.p);
+      VI_HIP(hipGetLastError());
+    }
   }
   const uint32_t one_first[1] = {0u}, one_len[1] = {(uint32_t)ix->nlists};
   VI_TRY(ix->c_first.reserve(1));
@@ -1874,6 +1936,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
+    { const char *e = getenv("VI_EXACT_BF16"); if (ix.lists_hi_nat.p && !(e && *e == '0')) a.c.hi_nat = (const uint4 *)ix.lists_hi_nat.p; }
     const size_t qsm = 4ull * ix.dim * sizeof(float);
     if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
     else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
