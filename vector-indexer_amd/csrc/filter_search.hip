@@ -346,7 +346,8 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
   }
 }
 
-__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo);
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo,
+                                     uint32_t *zero, uint32_t zero_words);
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
@@ -674,8 +675,11 @@ struct WideArgs {
 // -2 q split hi / lo, query-major, hi plane first: piece (plane p, chunk c, half h) of query q at q * 4 nc + p * 2 nc + 2 c + h
 // (a batch of bf16-exact queries is ranked from its hi planes alone: they are whole cache lines of their own)
 // *any_lo is raised when some query has a non-zero lo plane (a batch of bf16-exact queries is ranked without them)
-__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo) {
+// (`zero`: a buffer the next kernels count into — the coarse step's per-list histogram — cleared here instead of by a memset launch)
+__global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo,
+                                     uint32_t *zero, uint32_t zero_words) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (query, chunk, half)
+  for (uint64_t i = t; i < zero_words; i += (uint64_t)gridDim.x * blockDim.x) zero[i] = 0u;
   if (t >= (uint64_t)nq * nc * 2) return;
   const uint32_t h = (uint32_t)(t & 1u);
   const uint64_t qc = t >> 1;
@@ -1645,12 +1649,12 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
 // coarse quantizer on the matrix cores: the centroid table is one "list" probed by every query.
 // Leaves probes / gorder and the per-list histogram (ws.cnt) behind, like stage_coarse.
 vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, uint32_t list_segb0,
-                              hipStream_t st) {
+                              hipStream_t st, bool histogram_cleared = false) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
   VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
-  VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
+  if (!histogram_cleared) VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
   // one list, every query probes it: groups of 128 queries x segments of segb blocks
@@ -1725,7 +1729,8 @@ static uint32_t list_segb0() {
 }
 
 // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
-static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint64_t nq, hipStream_t st) {
+static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint64_t nq, hipStream_t st, uint32_t *zero = nullptr,
+                                   uint64_t zero_words = 0) {
   if (!rank_bf16()) return VI_OK;
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t nc = ix.dq / 4;
@@ -1737,7 +1742,7 @@ static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint6
   }
   const uint64_t nt = (uint64_t)nq * nc * 2;
   hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
-                     (uint4 *)ws.qimg.p, (unsigned long long *)(ws.stats.p + 13));
+                     (uint4 *)ws.qimg.p, (unsigned long long *)(ws.stats.p + 13), zero, (uint32_t)zero_words);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -1767,11 +1772,19 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
-  VI_TRY(build_query_image(ix, Qd, nq, st));
+  const char *cf = getenv("VI_COARSE_FILTER");
+  const bool coarse_mfma = !probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024 && ix.dim <= kNarrowDim && rank_bf16();
+  if (coarse_mfma) {  // (its per-list histogram is cleared by the kernel that splits the queries)
+    VI_TRY(ws.cnt.reserve(2 * subbin_words(nlists)));
+    VI_TRY(build_query_image(ix, Qd, nq, st, ws.cnt.p, subbin_words(nlists)));
+  } else {
+    VI_TRY(build_query_image(ix, Qd, nq, st));
+  }
   // ---- 1. coarse quantizer: probes, shard visiting order, per-list histogram, record offsets ----
   {
-    const char *cf = getenv("VI_COARSE_FILTER");
-    if (!probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024 && ix.dim <= kNarrowDim) {
+    if (coarse_mfma) {
+      VI_TRY(stage_coarse_filter(ix, Qd, nq, P, segb0, st, true));
+    } else if (!probes_in && !(cf && *cf == '0') && nq >= 256 && nlists >= 1024 && ix.dim <= kNarrowDim) {
       VI_TRY(stage_coarse_filter(ix, Qd, nq, P, segb0, st));
     } else {
       if (probes_in) VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, true, st));

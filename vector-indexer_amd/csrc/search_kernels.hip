@@ -370,8 +370,11 @@ __global__ void __launch_bounds__(kBlockThreads) coarse_merge_kernel(CoarseMerge
 //   segrun_start Σ cnt * nseg [nseg > 1]    (segment runs awaiting seg_merge_kernel)
 // stats[0] = Σ cnt*len, stats[1] = items, stats[2] = segment runs
 // queries probing every list: the sum of its sub-bin counters (one thread per list: coalesced along each sub-bin row)
-__global__ void list_totals_kernel(const uint32_t *cnt, uint32_t nlists, uint32_t *tot) {
+// (also resets the counters group_scan_kernel adds to — stats[0..5] and [12] — when `stats` is given: two memset
+// launches less on a path made of 5-microsecond kernels)
+__global__ void list_totals_kernel(const uint32_t *cnt, uint32_t nlists, uint32_t *tot, uint64_t *stats) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (stats && l < 7) stats[l < 6 ? l : 12] = 0;
   if (l >= nlists) return;
   const uint32_t st = subbin_stride(nlists);
   uint32_t c = 0;
@@ -1093,12 +1096,13 @@ vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, ui
 // pipeline stages
 // ------------------------------------------------------------------------------------------
 // histogram (ws.cnt) -> totals -> offsets of the lists in pairs / items / records -> scatter cursors
-static vi_status launch_group_scan(const DeviceIndex &ix, uint32_t qg, uint32_t segb0, uint32_t *tile_start, hipStream_t st) {
+static vi_status launch_group_scan(const DeviceIndex &ix, uint32_t qg, uint32_t segb0, uint32_t *tile_start, hipStream_t st,
+                                   bool reset_stats = false) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t nlists = (uint32_t)ix.nlists;
   VI_TRY(ws.list_tot.reserve(std::max<uint32_t>(1, nlists)));
   const dim3 grid((nlists + 255) / 256), block(256);
-  hipLaunchKernelGGL(list_totals_kernel, grid, block, 0, st, ws.cnt.p, nlists, ws.list_tot.p);
+  hipLaunchKernelGGL(list_totals_kernel, grid, block, 0, st, ws.cnt.p, nlists, ws.list_tot.p, reset_stats ? ws.stats.p : nullptr);
   hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.list_tot.p, ix.list_len.p, nlists, qg, segb0,
                      ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p, tile_start);
   hipLaunchKernelGGL(cursor_kernel, grid, block, 0, st, ws.cnt.p, ws.seg_start.p, nlists, ws.cnt.p + subbin_words(nlists));
@@ -1387,14 +1391,13 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pair_pos.reserve(total));
   VI_TRY(ws.tile_start.reserve(nlists + 1));
   VI_TRY(ws.stats.reserve(16));
-  VI_HIP(hipMemsetAsync(ws.stats.p, 0, 6 * sizeof(uint64_t), st));  // [6] .. [11] belong to the MFMA path's select
-  VI_HIP(hipMemsetAsync(ws.stats.p + 12, 0, sizeof(uint64_t), st));
+  // (stats[0..5] and [12] are reset by list_totals_kernel; [6] .. [11] belong to the MFMA path's select)
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                        (uint32_t)nlists, total, P, ws.cnt.p);
   }
-  VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st));
+  VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st, true));
   // the host waits for the counts (grid size, scratch) while the scatter runs
   VI_HIP(hipMemcpyAsync(hstats, ws.stats.p, 14 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.cur().ev[5], st));
