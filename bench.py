@@ -135,7 +135,8 @@ def roofline_of(st, scan_ms, d, world_note=""):
         peak = MFMA_F32_PEAK_TF if mode == 1 else MFMA_BF16_PEAK_TF
         name = {1: "filter_kernel<NG,1,false,0,GQ> (f32 MFMA ranking)",
                 2: "filter_kernel<NG,1,false,1,GQ> (bf16 MFMA ranking, operands split hi+lo: 3 MFMAs per 16 dims)",
-                3: "filter_kernel<NG,2,false,2,GQ> (bf16 MFMA ranking, hi planes only: stored values are bf16-exact)"}[mode]
+                3: "rank_stream_kernel<NC,2,QLO,NU> (bf16 MFMA ranking, hi planes only: stored values are bf16-exact; queries in LDS, "
+                   "vectors through registers, persistent workgroups)"}[mode]
         return {"kernel": name + " of (query group x list segment) tiles", "bound": "mfma", "achieved": round(tf, 1),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
                 "flops_per_launch": flops, "avg_launch_ms": round(scan_ms, 4), "tiles_per_launch": int(st["filter_tile_blocks"]),

@@ -25,7 +25,7 @@ shutil.copy(kt, f"profiles/{tag}_bench_kernel_stats.csv")
 
 
 # dominant kernel of the pipeline: the MFMA list ranking when the MFMA path ran, else the VALU list scan
-KERNEL = r"filter_kernel<\d+, \d+, false, \d+, \d+>|scan_kernel<\d+, 0, false, false>"
+KERNEL = r"rank_stream_kernel<\d+, \d+, (false|true), \d+>|filter_kernel<\d+, \d+, false, \d+, \d+>|scan_kernel<\d+, 0, false, false>"
 
 
 def scan_avg(pattern, counter):
@@ -42,7 +42,7 @@ fetch, n1, name = scan_avg(f"gpurun_out/prof_{tag}_fetch/*/*_counter_collection.
 write, n2, _ = scan_avg(f"gpurun_out/prof_{tag}_write/*/*_counter_collection.csv", "WRITE_SIZE")
 stats = {r["Name"]: r for r in csv.DictReader(open(kt))}
 scan = stats[name]
-m = re.search(r"filter_kernel<\d+, \d+, false, (\d+), \d+>", name)
+m = re.search(r"filter_kernel<\d+, \d+, false, (\d+), \d+>", name) or re.search(r"rank_stream_kernel<\d+, (\d+), ", name)
 out = {"workload": workload, "kernel": name, "rank_mode": (int(m.group(1)) + 1) if m else 0, "fetch_size_kib_avg": fetch, "write_size_kib_avg": write,
        "hbm_bytes_per_launch": int((2.0 * fetch + write) * 1024),
        "avg_launch_ns_rocprof": float(scan["AverageNs"]), "calls": int(scan["Calls"]),
