@@ -264,8 +264,9 @@ __global__ void item_cols_kernel(const uint4 *items, const uint32_t *pairs, cons
   const uint4 d0 = items[2 * (size_t)w], d1 = items[2 * (size_t)w + 1];
   if (threadIdx.x == 0) {
     sdesc[w] = make_uint4(d0.y, d0.z + d0.w, 2u * (d1.x - d0.w), d1.z);  // queries, first block, tiles, first record tile
-    if (w == 0) { stats[13] = 0; stats[14] = 0; }
+    if (w == 0) stats[13] = 0;
   }
+  if (w == 0 && threadIdx.x < 8) stats[16 + 16 * threadIdx.x] = 0;  // the rank kernel's work counters (one per XCD queue, 128 bytes apart)
   for (uint32_t col = threadIdx.x; col < gq; col += blockDim.x) {
     uint32_t q = ~0u, g = ~0u;
     if (col < d0.y) {
@@ -1672,7 +1673,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
   const char *de = getenv("VI_COARSE_DIRECT");
   const bool direct = ix.centroids.nblocks <= kDirectBlocks && !(de && *de == '0');
   VI_TRY(ws.brec.reserve((uint64_t)ngroups * (direct ? 2 * ix.centroids.nblocks : (uint64_t)nseg * seg_records(segb)) * 256 * 4));
-  VI_TRY(ws.stats.reserve(16));
+  VI_TRY(ws.stats.reserve(160));
   if (ws.c_nq != nq) {  // the table's one-list grouping depends on the batch size only
     VI_HIP(hipMemcpyAsync(ws.c_seg.p, h_seg, 8, hipMemcpyHostToDevice, st));
     VI_HIP(hipMemcpyAsync(ws.c_item.p, h_item, 8, hipMemcpyHostToDevice, st));
@@ -1736,8 +1737,8 @@ static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint6
   const uint32_t nc = ix.dq / 4;
   VI_TRY(ws.qimg.reserve((uint64_t)nq * nc * 4 * 4));  // uint32 words: 4 pieces of 16 B per (query, chunk)
   if (!ws.stats_zeroed) {  // [13]: some query has a lo plane (read back with the grouping's counts); [14]: the rank kernel's
-    VI_TRY(ws.stats.reserve(16));  // work counter — both reset by item_cols_kernel after their use
-    VI_HIP(hipMemsetAsync(ws.stats.p, 0, 16 * sizeof(uint64_t), st));
+    VI_TRY(ws.stats.reserve(160));  // work counter — both reset by item_cols_kernel after their use
+    VI_HIP(hipMemsetAsync(ws.stats.p, 0, 160 * sizeof(uint64_t), st));
     ws.stats_zeroed = true;
   }
   const uint64_t nt = (uint64_t)nq * nc * 2;
@@ -1768,7 +1769,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.pair_rel.reserve(nq * P));
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
-  VI_TRY(ws.stats.reserve(16));
+  VI_TRY(ws.stats.reserve(160));
   if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
@@ -1894,7 +1895,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
         VI_HIP(hipGetLastError());
       }
       RankStreamArgs a{(const uint4 *)ix.lists_bf16.p, ix.xnorm_img.p, (const uint4 *)ws.qimg.p, (const uint4 *)ws.item_sdesc.p, nitems,
-                       ws.item_qcol.p, ws.item_grec.p, (uint32_t *)(ws.stats.p + 14), (float4 *)ws.gval.p,
+                       ws.item_qcol.p, ws.item_grec.p, (uint32_t *)(ws.stats.p + 16), (float4 *)ws.gval.p,
                        (float4 *)ws.brec.p, nullptr, env_xmode()};
       const bool qlo = hstats[13] != 0 || !hi_only_ok();
       const bool prof = getenv("VI_STREAM_PROF") != nullptr;

@@ -207,13 +207,33 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
   };
 
   const unsigned long long rt_begin = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull;  // (100 MHz, chip-wide)
+  // Eight queues, one per XCD (workgroup b runs on XCD b % 8): queue x holds items [x n / 8, (x + 1) n / 8).  Items are
+  // numbered list by list, segment by segment, so the query groups of one list segment — which stream the same blocks —
+  // are taken by workgroups of one XCD at about the same time and share its L2.  A queue that has run dry sends the
+  // workgroup on to the next one.  Counter x at a.queue[32 x] (a cache line of its own).
+  constexpr uint32_t kQueues = 8;
+  auto queue_range = [&](uint32_t q, uint32_t &lo, uint32_t &hi) {
+    lo = (uint32_t)(((uint64_t)a.nitems * q) / kQueues);
+    hi = (uint32_t)(((uint64_t)a.nitems * (q + 1)) / kQueues);
+  };
+  uint32_t my_queue = blockIdx.x % kQueues;   // (thread 0's view: the queue it pops from)
+  auto resolve = [&](uint32_t popped) {       // thread 0: popped value of my_queue -> item index, or the next queue's, ... or none
+    for (uint32_t tries = 0; tries < kQueues; ++tries) {
+      uint32_t lo, hi;
+      queue_range(my_queue, lo, hi);
+      if (popped < hi - lo) return lo + popped;
+      my_queue = (my_queue + 1) % kQueues;
+      if (tries + 1 < kQueues) popped = atomicAdd(a.queue + 32 * my_queue, 1u);
+    }
+    return a.nitems;  // every queue is empty
+  };
   // ---- pipeline fill: two item indices, their descriptions, the first item's queries and first tile.  A workgroup holds
   //      its current item and the next; the one after is claimed during the current item's last step — items claimed
   //      early cannot be taken by a workgroup that runs dry, and the launch ends with its slowest workgroup ----
   const bool fixed = (a.xmode & 64u) != 0u;  // ablation: items dealt by stride instead of the counter
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (uint32_t k = 0; k < 2; ++k) s_idx[k] = fixed ? blockIdx.x + k * gridDim.x : atomicAdd(a.queue, 1u);
+    for (uint32_t k = 0; k < 2; ++k) s_idx[k] = fixed ? blockIdx.x + k * gridDim.x : resolve(atomicAdd(a.queue + 32 * my_queue, 1u));
   }
   __syncthreads();
   uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idx[0]), nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idx[1]);
@@ -257,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
       if ((uint32_t)wave < in.ntiles) load_tile<NC, NA>(spare, a.img, a.xnorm, in.blk00 + ((uint32_t)wave >> 1), (uint32_t)wave & 1u, j, h);
       // (asm: the compiler turns atomicAdd under a one-lane branch into its wave-aggregated form, which waits for the
       // result — and every older load of the wave — on the spot; the result is needed at the item's end)
-      if (threadIdx.x == 0) after = fixed ? nxt + gridDim.x : queue_pop_asm(a.queue);
+      if (threadIdx.x == 0) after = fixed ? nxt + gridDim.x : queue_pop_asm(a.queue + 32 * my_queue);
       if (DB) gather(buf ^ 1u, in.nqi, rn.qid);
     };
     const uint32_t nqi = ic.nqi, nu = (ic.nqi + 31u) >> 5, ntiles = ic.ntiles, blk00 = ic.blk00;
@@ -380,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     // the next item's queries and first tile have landed; with two images they are older than the last step's stores
     if (DB) wait_vmcnt(young_stores);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) s_idx[0] = after;  // (behind the wait: queue_pop_asm's result has arrived)
+    if (threadIdx.x == 0) s_idx[0] = fixed ? after : resolve(after);  // (behind the wait: queue_pop_asm's result has arrived)
     lap(10);
     __syncthreads();
     lap(2);

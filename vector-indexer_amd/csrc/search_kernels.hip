@@ -1299,7 +1299,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     Qd = ws.q.p; Dd = ws.D.p; Id = ws.I.p; Td = nullptr;
   }
   VI_TRY(ws.counts.reserve(nq));
-  VI_TRY(ws.stats.reserve(16));
+  VI_TRY(ws.stats.reserve(160));
   uint64_t *slots = nullptr;
   if (io.V) { VI_TRY(ws.slots.reserve(nq * k)); slots = ws.slots.p; }
 
@@ -1390,7 +1390,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   VI_TRY(ws.pairs.reserve(total));
   VI_TRY(ws.pair_pos.reserve(total));
   VI_TRY(ws.tile_start.reserve(nlists + 1));
-  VI_TRY(ws.stats.reserve(16));
+  VI_TRY(ws.stats.reserve(160));
   // (stats[0..5] and [12] are reset by list_totals_kernel; [6] .. [11] belong to the MFMA path's select)
   if (!histogram_done) {  // the coarse step of the fast paths leaves the histogram behind
     VI_HIP(hipMemsetAsync(ws.cnt.p, 0, subbin_words(nlists) * sizeof(uint32_t), st));
