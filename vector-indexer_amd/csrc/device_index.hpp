@@ -102,6 +102,7 @@ struct DeviceIndex {
   bool lists_lo_zero = false, cent_lo_zero = false;  // every stored value is bf16-exact (lo planes all zero)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   DevBuf<float> cent_xnorm;           // same for the coarse table
+  DevBuf<float> cent_rows;            // the coarse table row-major (coarse select: single-row exact re-evaluation)
   float cent_xmax2 = 0.0f;
   DevBuf<uint32_t> c_first, c_len;    // the coarse table described as one list
   hipStream_t stream = nullptr;       // uploads and index construction

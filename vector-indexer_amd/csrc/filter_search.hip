@@ -145,6 +145,16 @@ __global__ void hi_natural_kernel(const uint4 *img, uint32_t nc, uint64_t nblock
   out[((b * nc + c) * 2 + h) * 64 + v] = img[(((b * nc + c) * 4) + h) * 64 + image_column(v)];
 }
 
+// The coarse table once more, row-major (centroid c = dim consecutive floats): the coarse select re-evaluates ONE
+// centroid per candidate sub-block, and a lone row of a lane-interleaved block is 16 bytes in each of dim / 4 cache
+// lines; from this copy it is dim / 32 whole lines.  (k' x dim floats; the lists stay lane-interleaved only.)
+__global__ void rows_from_blocks_kernel(const float4 *blocks, uint32_t dq, uint32_t nrows, uint32_t nquad, float4 *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)nrows * nquad) return;
+  const uint32_t row = (uint32_t)(t / nquad), qd = (uint32_t)(t % nquad);
+  out[t] = blocks[((size_t)(row / 64) * dq + qd) * 64 + (row % 64)];
+}
+
 // any nonzero lo half in an image? (pieces of 64 uint4: plane = (piece >> 1) & 1)
 __global__ void lo_plane_any_kernel(const uint4 *img, uint64_t npieces, uint32_t *any) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -598,9 +608,16 @@ __global__ void __launch_bounds__(GQ * 2, GQ == 32 ? (RANK == 2 ? 2 : 1) : ((NBU
         nstores = qlive ? 2u : 0u;
         if (qlive) {
           const float2 s00 = tile_min8_idx(acc0, 0), s01 = tile_min8_idx(acc0, 8), s10 = tile_min8_idx(acc1, 0), s11 = tile_min8_idx(acc1, 8);
-          float4 *dst = a.brec + ((size_t)chunk * nblk + blk) * (4u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
-          dst[0] = make_float4(s00.x, s00.y, s01.x, s01.y);
-          dst[2u * GQ] = make_float4(s10.x, s10.y, s11.x, s11.y);
+          if (a.direct == 2u) {
+            // query-major: the select reads a query's records as 1 KB runs (these stores pay for it: 32 queries x 32 bytes each)
+            float4 *dst = a.brec + ((size_t)chunk * GQ + jq_grp) * (4u * nblk) + 4u * blk + (uint32_t)h;
+            dst[0] = make_float4(s00.x, s00.y, s01.x, s01.y);
+            dst[2] = make_float4(s10.x, s10.y, s11.x, s11.y);
+          } else {
+            float4 *dst = a.brec + ((size_t)chunk * nblk + blk) * (4u * GQ) + (uint32_t)GQ * (uint32_t)h + jq_grp;
+            dst[0] = make_float4(s00.x, s00.y, s01.x, s01.y);
+            dst[2u * GQ] = make_float4(s10.x, s10.y, s11.x, s11.y);
+          }
         }
       } else if (!(a.xmode & 2u)) {
         // all that is kept of the two 16-row sub-blocks: their minima
@@ -885,6 +902,30 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
   return acc;
 }
 
+// the same sum for a vector stored as dim consecutive floats (coarse table, rows_from_blocks_kernel)
+__device__ __forceinline__ float exact_pair_row(const float *qrow, const float4 *xr, uint32_t dim) {
+  const float4 *xq = reinterpret_cast<const float4 *>(qrow);
+  float acc = 0.0f;
+  const uint32_t nquad = dim >> 2;
+  uint32_t qd = 0;
+  for (; qd + 8 <= nquad; qd += 8) {
+    float4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xr[qd + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 qq = xq[qd + i];
+      sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
+    }
+  }
+  for (; qd < nquad; ++qd) {
+    const float4 qq = xq[qd];
+    const float4 xx = xr[qd];
+    sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
+  }
+  return acc;
+}
+
 // the same sum from the natural-order bf16 hi plane of bf16-exact vectors (hi_natural_kernel): x = bf16 << 16 exactly,
 // so every term and the sequential order are those of exact_pair; 16 bytes carry 8 dimensions
 __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 *xh, uint32_t dim) {
@@ -927,6 +968,15 @@ __device__ __attribute__((noinline)) Top exact_batch_fn(Top sel, const float *qr
                                                         uint32_t key, int K) {
   float d = INFINITY;
   if (live) d = exact_pair(qrow, xv, dim);
+  sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
+}
+
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_row_fn(Top sel, const float *qrow, const float4 *xr, uint32_t dim, bool live,
+                                                            uint32_t key, int K) {
+  float d = INFINITY;
+  if (live) d = exact_pair_row(qrow, xr, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
   return sel;
 }
@@ -1256,6 +1306,8 @@ struct CoarseSelectArgs {
   uint32_t nq, P, nlists, segb, recs;  // recs = group records per query
   const uint32_t *list_shard, *list_len;
   uint32_t *probes, *gorder, *cnt;
+  uint32_t query_major;  // direct records laid out [query][record] (filter_kernel: a.direct == 2)
+  const float4 *cent_rows;  // the table row-major (rows_from_blocks_kernel) for single-row re-evaluation, or null
   // record counts of the list phase (what pair_groups_kernel computes otherwise)
   uint32_t list_segb0;
   uint32_t *rel, *qtot;
@@ -1345,7 +1397,9 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   auto record = [&](uint32_t i) {
     const uint32_t rec = i * kWave + lane;  // block rec >> 2, tile (rec >> 1) & 1, lane half rec & 1
     float4 r = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    if (rec < nrec) r = c.brec[base + (size_t)(rec >> 2) * (4u * c.gq) + (size_t)((rec >> 1) & 1u) * (2u * c.gq) + c.gq * (rec & 1u)];
+    if (rec < nrec)
+      r = a.query_major ? c.brec[(size_t)q * nrec + rec]
+                        : c.brec[base + (size_t)(rec >> 2) * (4u * c.gq) + (size_t)((rec >> 1) & 1u) * (2u * c.gq) + c.gq * (rec & 1u)];
     return r;
   };
   // bound of the K-th distance: every lane's smallest minimum belongs to a different centroid, so K centroids are at
@@ -1385,8 +1439,14 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
     while (npick > 0) {
       const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
       npick -= cnt;
-      const bool live = (uint32_t)lane < cnt;
-      exact_rows(live, live ? pick[npick + lane] : 0u);
+      bool live = (uint32_t)lane < cnt;
+      const uint32_t pos = live ? pick[npick + lane] : 0u;
+      if (a.cent_rows) {  // one centroid per lane, each its own whole cache lines
+        live = live && pos < a.nlists && !(c.xmode & 1u);
+        sel = exact_batch_row_fn(sel, qlds, a.cent_rows + (size_t)(live ? pos : 0u) * (c.dim / 4), c.dim, live, pos, (int)K);
+      } else {
+        exact_rows(live, pos);
+      }
     }
   };
   auto drain_whole = [&]() {  // 8 sub-blocks x 8 rows per round
@@ -1632,6 +1692,14 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
     VI_HIP(hipStreamSynchronize(ix->stream));
     ix->lists_lo_zero = np_l > 0 && h_any[0] == 0;
     ix->cent_lo_zero = np_c > 0 && h_any[1] == 0;
+    if (ix->nlists && ix->dim <= kNarrowDim) {  // single-row exact re-evaluation of the coarse select
+      const uint32_t nquad = ix->dim / 4;
+      VI_TRY(ix->cent_rows.reserve((uint64_t)ix->nlists * ix->dim));
+      const uint64_t nt = (uint64_t)ix->nlists * nquad;
+      hipLaunchKernelGGL(rows_from_blocks_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->centroids.blocks.p, ix->dq, (uint32_t)ix->nlists, nquad, (float4 *)ix->cent_rows.p);
+      VI_HIP(hipGetLastError());
+    }
     if (ix->lists_lo_zero && ix->dim <= kNarrowDim) {  // exact re-evaluation from bf16 (select_kernel), VI_EXACT_BF16=0: from f32
       VI_TRY(ix->lists_hi_nat.reserve(ix->lists.nblocks * per_block / 2));
       hipLaunchKernelGGL(hi_natural_kernel, dim3((uint32_t)((nt_l + 255) / 256)), dim3(256), 0, ix->stream,
@@ -1682,6 +1750,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     VI_HIP(hipStreamSynchronize(st));  // h_seg / h_item live on this stack frame
     ws.c_nq = nq;
   }
+  bool qmajor = false;
   {
     FilterArgs a{};
     a.blocks = rank_bf16() ? (const float4 *)ix.cent_bf16.p : (const float4 *)ix.centroids.blocks.p;
@@ -1691,14 +1760,16 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     a.qoff = nullptr; a.rel = nullptr; a.rec_stride = recs;
     a.tile_start = ix.c_first.p;  // one list: its tiles start at 0 (c_first holds a single 0)
     a.gval = (float4 *)ws.gval.p; a.gmeta = ws.gpos.p; a.brec = (float4 *)ws.brec.p;
-    a.direct = direct ? 1u : 0u;
+    { const char *e = getenv("VI_COARSE_QMAJOR"); qmajor = direct && !(e && *e == '0'); }
+    a.direct = direct ? (qmajor ? 2u : 1u) : 0u;
     a.qimg = rank_bf16() ? (const uint4 *)ws.qimg.p : nullptr;
     VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
     CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2, kGroupQ), (uint32_t)nq, P,
                        (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
-                       ws.cnt.p, list_segb0, ws.pair_rel.p, ws.qtot.p};
+                       ws.cnt.p, qmajor ? 1u : 0u, nullptr, list_segb0, ws.pair_rel.p, ws.qtot.p};
+    { const char *e = getenv("VI_COARSE_ROWS"); if (ix.cent_rows.p && !(e && *e == '0')) a.cent_rows = (const float4 *)ix.cent_rows.p; }
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
     if (direct) a.c.e_scale += (float)(1.01 * std::ldexp(1.0, -20));  // the row index rides in 3 mantissa bits of the minima
