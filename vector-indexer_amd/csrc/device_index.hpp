@@ -75,6 +75,7 @@ struct SearchWorkspace {
   DevBuf<float> brec;                       // pair records: the 4 sub-block minima of two blocks per (record tile, lane half, query of the group)
   struct GqHint { uint64_t nq; uint32_t P, gq; };
   std::vector<GqHint> gq_hint;              // queries per rank work item measured to suit a batch shape (filter_search.hip)
+  uint64_t *hstats_pinned = nullptr;        // page-locked landing buffer of the grouping's counts (16 words)
   bool stats_zeroed = false;                // stats[13], [14] start at zero (filter_search.hip)
   bool queries_hi_only = false;             // the previous batch's -2 q were all bf16-exact (no lo plane)
   DevBuf<uint64_t> sort_keys, order_keys, total;
