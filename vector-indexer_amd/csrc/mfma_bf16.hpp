@@ -100,6 +100,12 @@ __device__ __forceinline__ void glds16_at(const void *gsrc, unsigned lds_addr) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+__device__ __forceinline__ void glds4_at(const void *gsrc, unsigned lds_addr) {  // 4 bytes per lane
+  unsigned keep;
+  const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
 __device__ __forceinline__ void glds4_asm(const void *gsrc, float *lds_dst) {
   unsigned keep;
   const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(lds_ptr_t)lds_dst);
