@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
   constexpr bool DB = stream_double_buffered(IMG);
   static_assert(RANK == 2 || QLO, "bf16 x 3 needs the queries' lo plane");
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float *s_T = s_mem + (DB ? 2 : 1) * (IMG / 4);             // [wave][query tile][lane]: the waves' minima of an item
-  uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_T + 4 * NU * kWave);  // item indices handed from wave 0 to the others
+  float *s_T = s_mem + (DB ? 2 : 1) * (IMG / 4);             // [item parity][wave][query tile][lane]: the waves' minima of an item
+  uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_T + 2 * 4 * NU * kWave);  // item indices handed from wave 0 to the others ([parity])
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const unsigned lds_q = (unsigned)(size_t)(lds_ptr_t)s_mem;  // LDS byte address of the query image(s)
@@ -262,6 +262,7 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     }
   };
   uint32_t buf = 0;  // image of the current item (DB)
+  uint32_t par = 0;  // parity of the current item (buffers of the item-end hand-over)
   uint32_t n_items = 0;
   // piece (plane p, chunk c, half h) of query 32 u + j: (row base | swizzle of the lane) XOR the piece (StreamLayout)
   const uint32_t lane_row = ((uint32_t)j * RP + L::swz(0u, (uint32_t)j)) * 16u;
@@ -388,19 +389,23 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     //      4 of the segment), sorted: four distinct sub-blocks' minima, the smallest of them the segment's minimum —
     //      all the select relies on (a bound from K listed values holds for any K distinct sub-blocks; pair records
     //      list the rest).  The segment's true four smallest would cost four registers per query tile and wave.
+    // One barrier per item with two images: a wave requests the queries of item k + 2 (into item k's image) in its last
+    // step of item k + 1, behind the barrier that ended item k for everyone; the minima and the handed-over index go
+    // through buffers of the item's parity, so a fast wave's next round cannot overtake a slow wave's reads.
     lap(0);
-    __syncthreads();  // every wave is done with the current query image
+    if (!DB) __syncthreads();  // (one image: every wave is done with it before the next item's queries overwrite it)
     lap(1);
+    float *s_Tk = s_T + par * (4 * NU * kWave);
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      if ((uint32_t)u < nu) s_T[(wave * NU + u) * kWave + lane] = T[u];
+      if ((uint32_t)u < nu) s_Tk[(wave * NU + u) * kWave + lane] = T[u];
     lap(8);
     if (!DB) gather(0u, in.nqi, rn.qid);
     lap(9);
     // the next item's queries and first tile have landed; with two images they are older than the last step's stores
     if (DB) wait_vmcnt(young_stores);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) s_idx[0] = fixed ? after : resolve(after);  // (behind the wait: queue_pop_asm's result has arrived)
+    if (threadIdx.x == 0) s_idx[par] = fixed ? after : resolve(after);  // (behind the wait: queue_pop_asm's result has arrived)
     lap(10);
     __syncthreads();
     lap(2);
@@ -414,8 +419,8 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     for (int r = 0; r < NR; ++r) {
       const uint32_t u = (uint32_t)wave + 4u * r;
       if (u < nu) {
-        float v0 = s_T[(0 * NU + u) * kWave + lane], v1 = s_T[(1 * NU + u) * kWave + lane];
-        float v2 = s_T[(2 * NU + u) * kWave + lane], v3 = s_T[(3 * NU + u) * kWave + lane];
+        float v0 = s_Tk[(0 * NU + u) * kWave + lane], v1 = s_Tk[(1 * NU + u) * kWave + lane];
+        float v2 = s_Tk[(2 * NU + u) * kWave + lane], v3 = s_Tk[(3 * NU + u) * kWave + lane];
         auto cx = [](float &x, float &y) { const float lo = fminf(x, y), hi = fmaxf(x, y); x = lo; y = hi; };
         cx(v0, v1); cx(v2, v3); cx(v0, v2); cx(v1, v3); cx(v1, v2);  // sort four
         if (rc.rec[r] != ~0u) a.gval[rc.rec[r] + (uint32_t)h] = make_float4(v0, v1, v2, v3);
@@ -423,7 +428,8 @@ __global__ void __launch_bounds__(256, 2) rank_stream_kernel(RankStreamArgs a) {
     }
     lap(11);
     cur = nxt;
-    nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idx[0]);
+    nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idx[par]);
+    par ^= 1u;
     ic = in;
     rc = rn;
     buf ^= 1u;
@@ -456,7 +462,7 @@ template <int NC, int RANK, bool QLO, int NU>
 vi_status launch_one(const RankStreamArgs &a, uint32_t nitems, hipStream_t st) {
   // LDS: the query image, the waves' minima of an item (1 KB per query tile), the item indices
   const size_t img = (size_t)StreamLayout<2 * NC * (QLO ? 2 : 1)>::RP * (32 * NU) * 16;
-  const size_t lds = img * (stream_double_buffered((int)img) ? 2 : 1) + (size_t)NU * 1024 + 16;
+  const size_t lds = img * (stream_double_buffered((int)img) ? 2 : 1) + 2 * (size_t)NU * 1024 + 16;
   static const bool ok = hipFuncSetAttribute((const void *)rank_stream_kernel<NC, RANK, QLO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds) == hipSuccess;
   if (!ok) return fail(VI_ERR_DEVICE, "cannot reserve %zu bytes of LDS for the rank kernel", lds);
