@@ -77,8 +77,8 @@ def test_rank_kernels_do_not_spill_and_keep_one_store_per_block(asm):
         loop = block_loop(k["body"])
         stores = re.findall(r"^\s*global_store_\w+", loop, re.M)
         # one pair-record store per block; the coarse-table instantiations also hold the two stores of the direct records
-        # (the two paths are exclusive and waited for with vmcnt(1) / vmcnt(2))
-        want = 3 if k["table"] else 1
+        # in their two layouts (by block / query-major) — three exclusive paths, waited for with vmcnt(1) / vmcnt(2)
+        want = 5 if k["table"] else 1
         assert stores == ["\tglobal_store_dwordx4"] * want, f"{name}: stores in the block loop: {stores}"
         loads = re.findall(r"^\s*global_load_(?!lds)\w+", loop, re.M)
         assert not loads, f"{name}: plain global loads inside the block loop: {loads}"
