@@ -70,7 +70,7 @@ SETTINGS = [
     ("gq256 x16", {"VI_STREAM_GQ": 256, "VI_FILTER_XMODE": 16}),
     ("gq256 segb 16", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 16}),
     ("gq256 segb 64", {"VI_STREAM_GQ": 256, "VI_FILTER_SEGB": 64}),
-    ("exact from f32", {"VI_EXACT_BF16": 0}),
+    ("exact from f32", {"VI_EXACT_BF16": 0, "VI_EXACT_U8": 0}),
     ("coarse records by block", {"VI_COARSE_QMAJOR": 0}),
     ("coarse rows from blocks", {"VI_COARSE_ROWS": 0}),
     ("s x1 tiles not re-read", {"VI_FILTER_XMODE": 1}),

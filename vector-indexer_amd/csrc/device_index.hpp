@@ -99,6 +99,7 @@ struct DeviceIndex {
   DevBuf<float> xnorm;                // [lists.nblocks*64] squared norm per slot (3e38 on pad slots)
   DevBuf<float> xnorm_img, cent_xnorm_img;  // the same in the column order of the bf16 images (filter_search.hip: image_column)
   DevBuf<uint32_t> lists_bf16, cent_bf16;  // bf16 hi/lo images of the blocks for the MFMA ranking (filter_search.hip)
+  DevBuf<uint32_t> lists_u8_nat;           // 8-bit descriptors (integers 0..255): one byte per dimension, same order (exact re-evaluation)
   DevBuf<uint32_t> lists_hi_nat;           // bf16-exact lists: their hi plane in the blocks' own vector order (exact re-evaluation)
   bool lists_lo_zero = false, cent_lo_zero = false;  // every stored value is bf16-exact (lo planes all zero)
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)

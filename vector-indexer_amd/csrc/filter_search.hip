@@ -155,6 +155,36 @@ __global__ void rows_from_blocks_kernel(const float4 *blocks, uint32_t dq, uint3
   out[t] = blocks[((size_t)(row / 64) * dq + qd) * 64 + (row % 64)];
 }
 
+// 8-bit descriptors (every stored value an integer in 0..255, as SIFT's): one byte per dimension, 16 dimensions of vector
+// v at (block * ceil(dq / 4) + p) * 64 + v — a 16-vector sub-block is re-evaluated from 256 contiguous bytes per 16
+// dimensions, half of the bf16 copy again.  `not_u8` is raised if some value does not fit.
+__global__ void u8_check_kernel(const float4 *blocks, uint64_t nquads, uint32_t *not_u8) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (t < nquads) {
+    const float4 v = blocks[t];
+    auto ok = [](float x) { return x >= 0.0f && x <= 255.0f && x == floorf(x); };
+    bad = !(ok(v.x) && ok(v.y) && ok(v.z) && ok(v.w));
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(not_u8, 1u);
+}
+__global__ void u8_natural_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, uint4 *out) {
+  const uint32_t np = (dq + 3) / 4;  // pieces of 16 dimensions (dq is a multiple of 4)
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block, piece, vector)
+  if (t >= nblocks * np * 64) return;
+  const uint32_t v = (uint32_t)(t & 63);
+  const uint64_t bp = t >> 6;
+  const uint32_t p = (uint32_t)(bp % np);
+  const uint64_t b = bp / np;
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 x = blocks[(b * dq + 4 * p + i) * 64 + v];
+    w[i] = (uint32_t)x.x | ((uint32_t)x.y << 8) | ((uint32_t)x.z << 16) | ((uint32_t)x.w << 24);
+  }
+  out[t] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // any nonzero lo half in an image? (pieces of 64 uint4: plane = (piece >> 1) & 1)
 __global__ void lo_plane_any_kernel(const uint4 *img, uint64_t npieces, uint32_t *any) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -862,6 +892,7 @@ struct SelectCommon {
   unsigned long long *dbg;  // [6] exact re-evaluations, [7] groups whose pair records were read, [8..] see select_body
   uint32_t image_order;     // the rank kernel multiplied the permuted bf16 image (subblock_vector)
   const uint4 *hi_nat;      // bf16-exact lists: natural-order hi plane for the exact re-evaluation (hi_natural_kernel), else null
+  const uint4 *u8_nat;      // 8-bit descriptors: one byte per dimension (u8_natural_kernel), else null
   uint32_t wave_order;      // pair records in the streaming kernel's wave order (scan.hpp: seg_records), else pair order
   uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
 };
@@ -953,6 +984,34 @@ __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 
   return acc;
 }
 
+// ... and from one byte per dimension (u8_natural_kernel): x = (float)byte exactly
+__device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *xb, uint32_t dim) {
+  float acc = 0.0f;
+  const uint32_t npiece = (dim + 15u) >> 4;  // (dim % 4 == 0: the last piece may hold 4, 8 or 12 dimensions)
+  auto word = [&](uint32_t w, uint32_t e) {   // 4 dimensions starting at e
+    const float4 q = *reinterpret_cast<const float4 *>(qrow + e);
+    sq_add(acc, q.x, (float)(w & 0xFFu)); sq_add(acc, q.y, (float)((w >> 8) & 0xFFu));
+    sq_add(acc, q.z, (float)((w >> 16) & 0xFFu)); sq_add(acc, q.w, (float)(w >> 24));
+  };
+  auto piece = [&](const uint4 &x, uint32_t p) {
+    const uint32_t e = 16 * p;
+    word(x.x, e);
+    if (e + 4 < dim) word(x.y, e + 4);
+    if (e + 8 < dim) word(x.z, e + 8);
+    if (e + 12 < dim) word(x.w, e + 12);
+  };
+  uint32_t p = 0;
+  for (; p + 8 <= npiece; p += 8) {
+    uint4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(x[i], p + i);
+  }
+  for (; p < npiece; ++p) piece(xb[(size_t)p * kWave], p);
+  return acc;
+}
+
 // The select kernels are latency-sensitive code executed once per query; inlining the two heavy pieces at
 // every call site made them ~150 KB each and instruction-fetch bound.  They are real functions with their state
 // passed and returned in registers.
@@ -968,6 +1027,15 @@ __device__ __attribute__((noinline)) Top exact_batch_fn(Top sel, const float *qr
                                                         uint32_t key, int K) {
   float d = INFINITY;
   if (live) d = exact_pair(qrow, xv, dim);
+  sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
+}
+
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_u8_fn(Top sel, const float *qrow, const uint4 *xb, uint32_t dim, bool live, uint32_t key,
+                                                           int K) {
+  float d = INFINITY;
+  if (live) d = exact_pair_u8(qrow, xb, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
   return sel;
 }
@@ -1043,7 +1111,10 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     live = live && pos < len && !(c.xmode & 1u);
     n_exact += (uint32_t)__popcll(__ballot(live));
-    if (c.hi_nat)
+    if (c.u8_nat)
+      sel = exact_batch_u8_fn(sel, qrow, c.u8_nat + ((size_t)(fb + (live ? pos : 0u) / kWave) * (c.dq / 4)) * kWave + (pos % kWave), c.dim,
+                              live, (g << kPosBits) | pos, (int)K);
+    else if (c.hi_nat)
       sel = exact_batch_bf16_fn(sel, qrow, c.hi_nat + ((size_t)(fb + (live ? pos : 0u) / kWave) * (c.dq / 2)) * kWave + (pos % kWave),
                                 c.dim, live, (g << kPosBits) | pos, (int)K);
     else
@@ -1121,6 +1192,15 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     }
   };
 
+  // (diagnostic, VI_FILTER_STATS: s_memtime ticks per stage, summed over the queries into dbg[150..155])
+  unsigned long long tk = c.dbg ? __builtin_amdgcn_s_memtime() : 0ull, tks[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) {
+    if (c.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tks[i] += now - tk;
+      tk = now;
+    }
+  };
   // ---- stage 0: the first 256 group records go to LDS in one round of loads (the passes below would
   //      otherwise each pay the global-memory latency per 64 groups) ----
   {
@@ -1158,6 +1238,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     if (live) L = gidx < kCacheG ? lcache[gidx] : c.gmeta[gbase + gidx];
     r = L & 63u; seg = (L >> 6) & 127u; hh = L >> 13;
   };
+  lap(0);
   // ---- stage 1a: threshold (*) from the K-th smallest value of the group records (key = 4*group + slot);
   //      the groups' smallest values first: they shut the door on most of the others ----
   bool any_full = false;
@@ -1183,6 +1264,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
       any_full = any_full || __ballot(gidx < G && T.w <= thr) != 0ull;  // (distrust: thr = inf, stage 1b is moot)
     }
   }
+  lap(1);
   // ---- stage 1b: neighbours concentrated in few groups hide behind the 4 listed minima and leave the bound
   //      loose; the pair records of those groups list every sub-block minimum.  Their values REPLACE the
   //      group's own (which are among them, so they must not be counted twice): drop the group's entries from
@@ -1207,6 +1289,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     }
     thr = fminf(thr, threshold_of(s1.kth((int)K)));
   }
+  lap(2);
   // ---- stage 2: exact re-evaluation of every sub-block whose minimum is at or below thr; such a sub-block sits in a
   //      group whose smallest minimum is at or below thr ----
   for (uint32_t gb = 0; gb < G; gb += kWave) {
@@ -1218,8 +1301,12 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     n_full += (uint32_t)__popcll(__ballot(live && T.w <= thr));
     scan_groups(live && !(T.x > thr) && !(c.xmode & 2u), r, seg, hh, 1);
   }
+  lap(3);
   drain_pick();
+  lap(4);
   if (c.dbg && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) atomicAdd(&c.dbg[150 + i], tks[i]);
     atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
     atomicAdd(&c.dbg[7], (unsigned long long)n_scanned);
     atomicAdd(&c.dbg[8], (unsigned long long)(any_full ? 1u : 0u));
@@ -1593,6 +1680,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   c.image_order = rank_bf16() ? 1u : 0u;
   c.wave_order = wave_order ? 1u : 0u;
   c.hi_nat = nullptr;
+  c.u8_nat = nullptr;
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.cur().ws.stats.p : nullptr;
@@ -1700,7 +1788,23 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
                          (const float4 *)ix->centroids.blocks.p, ix->dq, (uint32_t)ix->nlists, nquad, (float4 *)ix->cent_rows.p);
       VI_HIP(hipGetLastError());
     }
-    if (ix->lists_lo_zero && ix->dim <= kNarrowDim) {  // exact re-evaluation from bf16 (select_kernel), VI_EXACT_BF16=0: from f32
+    if (ix->lists_lo_zero && ix->dim <= kNarrowDim && ix->lists.nblocks) {  // 8-bit descriptors?  (bf16-exact is necessary)
+      VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
+      const uint64_t nquads = ix->lists.nblocks * ix->dq * 64;
+      hipLaunchKernelGGL(u8_check_kernel, dim3((uint32_t)((nquads + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->lists.blocks.p, nquads, mx.p);
+      uint32_t not_u8 = 1;
+      VI_HIP(hipMemcpyAsync(&not_u8, mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
+      VI_HIP(hipStreamSynchronize(ix->stream));
+      if (!not_u8) {
+        const uint64_t nt8 = ix->lists.nblocks * (ix->dq / 4) * 64;
+        VI_TRY(ix->lists_u8_nat.reserve(nt8 * 4));
+        hipLaunchKernelGGL(u8_natural_kernel, dim3((uint32_t)((nt8 + 255) / 256)), dim3(256), 0, ix->stream,
+                           (const float4 *)ix->lists.blocks.p, ix->dq, ix->lists.nblocks, (uint4 *)ix->lists_u8_nat.p);
+        VI_HIP(hipGetLastError());
+      }
+    }
+    if (ix->lists_lo_zero && ix->dim <= kNarrowDim && !ix->lists_u8_nat.p) {  // exact re-evaluation from bf16 (select_kernel), VI_EXACT_BF16=0: from f32
       VI_TRY(ix->lists_hi_nat.reserve(ix->lists.nblocks * per_block / 2));
       hipLaunchKernelGGL(hi_natural_kernel, dim3((uint32_t)((nt_l + 255) / 256)), dim3(256), 0, ix->stream,
                          (const uint4 *)ix->lists_bf16.p, ix->dq / 4, ix->lists.nblocks, (uint4 *)ix->lists_hi_nat.p);
@@ -1841,7 +1945,10 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   VI_TRY(ws.qtot.reserve(nq));
   VI_TRY(ws.qoff.reserve(nq + 1));
   VI_TRY(ws.stats.reserve(160));
-  if (getenv("VI_FILTER_STATS")) VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
+  if (getenv("VI_FILTER_STATS")) {
+    VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
+    VI_HIP(hipMemsetAsync(ws.stats.p + 150, 0, 8 * sizeof(uint64_t), st));
+  }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
   const char *cf = getenv("VI_COARSE_FILTER");
@@ -2032,6 +2139,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
     { const char *e = getenv("VI_EXACT_BF16"); if (ix.lists_hi_nat.p && !(e && *e == '0')) a.c.hi_nat = (const uint4 *)ix.lists_hi_nat.p; }
+    { const char *e = getenv("VI_EXACT_U8"); if (ix.lists_u8_nat.p && !(e && *e == '0')) a.c.u8_nat = (const uint4 *)ix.lists_u8_nat.p; }
     const size_t qsm = 4ull * ix.dim * sizeof(float);
     if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
     else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
@@ -2039,9 +2147,14 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));
   if (timing && getenv("VI_FILTER_STATS")) {
-    uint64_t dbg[12];
+    uint64_t dbg[12], tks[8];
     VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
+    VI_HIP(hipMemcpyAsync(tks, ws.stats.p + 150, sizeof(tks), hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
+    if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
+      fprintf(stderr, "select ticks: records -> LDS %llu, threshold %llu, refinement %llu, scan of pair records (+ exact rounds it triggers) %llu, "
+              "last exact rounds %llu\n", (unsigned long long)tks[0], (unsigned long long)tks[1], (unsigned long long)tks[2],
+              (unsigned long long)tks[3], (unsigned long long)tks[4]);
     stt.filter_rechecked = dbg[6]; stt.filter_accepted = dbg[7];
     if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
       fprintf(stderr, "select stats: exact %llu groups_scanned %llu queries_with_full_group %llu full_groups %llu sub_blocks %llu\n",
