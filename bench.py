@@ -370,6 +370,34 @@ def main():
                 e = time_steps(small, 50, 5, barrier, world, device)
                 lat[str(b)] = {"ms_per_call": round(e * 1000.0 / 50, 4), "queries_per_s": round(b * 50 / e, 1)}
         extras["batch_latency"] = lat
+        # (c2) several host threads issuing batches on the one handle (the library holds four search contexts, each with its
+        # own stream: the reference's search is &self and runs concurrently, tests/ivf_index_tests.rs:768-807): batches
+        # overlap on the GPU — a serving process's throughput, not the headline (whose steps run one after the other)
+        import threading
+        conc = {}
+        index.search_device(xq.data_ptr(), nq, k, head, D.data_ptr(), I.data_ptr(), 0)  # single-thread reference for the comparison
+        torch.cuda.synchronize(device)
+        for nthreads in (2, 4):
+            outs = [(torch.empty_like(D), torch.empty_like(I)) for _ in range(nthreads)]
+            per = max(4, args.steps // 2)
+
+            def worker(t, reps):
+                for _ in range(reps):
+                    index.search_device(xq.data_ptr(), nq, k, head, outs[t][0].data_ptr(), outs[t][1].data_ptr(), 0)
+            for t in range(nthreads):
+                worker(t, 1)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(t, per)) for t in range(nthreads)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            torch.cuda.synchronize(device)
+            e = time.perf_counter() - t0
+            conc[str(nthreads)] = {"queries_per_s": round(nthreads * per * nq / e, 1), "ms_per_batch": round(e * 1000.0 / (nthreads * per), 4),
+                                   "identical_to_single_thread": bool(all(torch.equal(o[1], I) for o in outs))}
+        extras["concurrent_batches_one_handle"] = conc
         # (d) real-valued data takes the bf16 x 3 ranking (lo planes streamed): the same batch with that arithmetic
         os.environ["VI_FILTER_HI_ONLY"] = "0"
         e = time_steps(lambda: step(head), max(3, args.steps // 2), 2, barrier, world, device)
