@@ -496,10 +496,12 @@ def test_wide_vectors_run_on_the_mfma_engine(d, n, nlist, tmp_path):
     check_parity(orc, gpu, Q[:5], 10, 4)
 
 
-@pytest.mark.parametrize("n,d,nq,k,P", [(200, 8, 1, 1, 50), (3000, 8, 5, 3, 8), (3000, 32, 40, 10, 8), (20000, 128, 300, 10, 16),
-                                        (20000, 64, 700, 10, 16), (12000, 96, 260, 64, 32), (9000, 48, 129, 5, 4)])
+@pytest.mark.parametrize("n,d,nq,k,P,nlist", [(200, 8, 1, 1, 50, 0), (3000, 8, 5, 3, 8, 0), (3000, 32, 40, 10, 8, 0), (20000, 128, 300, 10, 16, 0),
+                                              (20000, 64, 700, 10, 16, 0), (12000, 96, 260, 64, 32, 0), (9000, 48, 129, 5, 4, 0),
+                                              (21000, 32, 150, 10, 4, 4),      # lists of ~80 blocks: three segments each
+                                              (160000, 16, 70, 10, 2, 1)])     # one list of 2 500 blocks: segments of 40 blocks, 20 pair records
 @pytest.mark.parametrize("variant", ["stream-128", "stream-256", "block-synchronous"])
-def test_streaming_rank_kernel_parity(n, d, nq, k, P, variant, tmp_path, monkeypatch):
+def test_streaming_rank_kernel_parity(n, d, nq, k, P, nlist, variant, tmp_path, monkeypatch):
     """bf16-exact (8-bit valued) data takes the streaming rank kernel (rank_stream.hip): groups of 128 queries with two
     query images, groups of 256 (an experiment knob; the first batch of a shape still runs 128), and the
     block-synchronous kernel it replaced — all three against the oracle, ids and distance bits; integer and
@@ -513,7 +515,7 @@ def test_streaming_rank_kernel_parity(n, d, nq, k, P, variant, tmp_path, monkeyp
     X = rng.integers(0, 200, size=(n, d)).astype(np.float32)
     if (n // 1000) % 2 == 0:
         X = X * 0.5 - 30.0   # bf16-exact but not 8-bit descriptors: the select re-evaluates from the bf16 copy, not the byte copy
-    orc, gpu = oracle_and_gpu(tmp_path, X)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
     Qi = np.ascontiguousarray(X[rng.integers(0, n, nq)] + rng.integers(-3, 4, size=(nq, d)), dtype=np.float32)
     Qf = np.ascontiguousarray(Qi + rng.random((nq, d), dtype=np.float32) * 0.37, dtype=np.float32)
     for Q in (Qi, Qi[::-1].copy(), Qf):
