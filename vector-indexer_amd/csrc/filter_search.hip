@@ -980,6 +980,13 @@ __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(x[i], p + i);
   }
+  for (; p + 4 <= npiece; p += 4) {  // (a half round: D = 96 has 6 / 12 pieces)
+    uint4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = xh[(size_t)(p + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece(x[i], p + i);
+  }
   for (; p < npiece; ++p) piece(xh[(size_t)p * kWave], p);
   return acc;
 }
@@ -1007,6 +1014,13 @@ __device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *x
     for (int i = 0; i < 8; ++i) x[i] = xb[(size_t)(p + i) * kWave];
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(x[i], p + i);
+  }
+  for (; p + 4 <= npiece; p += 4) {  // (a half round: D = 96 has 6 / 12 pieces)
+    uint4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece(x[i], p + i);
   }
   for (; p < npiece; ++p) piece(xb[(size_t)p * kWave], p);
   return acc;
@@ -1994,8 +2008,11 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   // 128 queries and costs MFMAs for its live 32-query tiles only, so there is no group size to choose (VI_STREAM_GQ=256:
   // groups of 256 when the queries are bf16-exact too — measured equal).  VI_RANK_STREAM=0: block-synchronous kernel.
   // (bf16 x 3 keeps the block-synchronous kernel: two tiles of hi + lo planes do not fit in the streaming kernel's registers)
-  const bool stream = ix.dim <= kNarrowDim && rank_bf16() && ix.lists_lo_zero && hi_only_ok() &&
-                      !(getenv("VI_RANK_STREAM") && *getenv("VI_RANK_STREAM") == '0');
+  // (measured at D = 32 / 64 / 96 / 128: its helper kernels and item skeleton pay off from 7 chunks of 16 dimensions on;
+  // VI_RANK_STREAM=1 forces it for any D <= 128)
+  const char *se = getenv("VI_RANK_STREAM");
+  const bool stream = ix.dim <= kNarrowDim && rank_bf16() && ix.lists_lo_zero && hi_only_ok() && !(se && *se == '0') &&
+                      (dq / 4 >= 7 || (se && *se == '1'));
   if (stream) {
     const char *e = getenv("VI_STREAM_GQ");
     gq = e && atoi(e) == 256 && ws.queries_hi_only ? 256u : 128u;
