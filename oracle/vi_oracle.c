@@ -571,8 +571,11 @@ int orc_kmeans_mini_batch(const float *X, size_t n, size_t d, size_t k, size_t m
     if (delta < thr) { ++it; break; }
   }
   if (iters_run) *iters_run = it;
-  if (force_brute) orc_assign_brute_force(X, n, d, C, k, labels);
-  else orc_assign(X, n, d, C, k, seed, labels);
+  /* labels == NULL: the caller checks the final assignment (:146-147) on sampled rows itself (tests at N = 1e7) */
+  if (labels) {
+    if (force_brute) orc_assign_brute_force(X, n, d, C, k, labels);
+    else orc_assign(X, n, d, C, k, seed, labels);
+  }
   free(counts); free(prev); free(perm); free(bidx); free(blab); free(Ccur); free(bsum);
   return ORC_OK;
 }

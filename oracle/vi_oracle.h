@@ -100,7 +100,8 @@ void orc_update_centroids(const float *X, size_t n, size_t d, const uint64_t *la
                           size_t k, float *C_new, uint64_t *counts);
 /* run_kmeans_mini_batch :64-150.  thr < 0 => None => 1e-4.
  * force_brute != 0 replaces the final assign by exact brute force (extension
- * used to check the GPU "exact" mode). iters_run (optional) = iterations done */
+ * used to check the GPU "exact" mode). iters_run (optional) = iterations done.
+ * labels == NULL skips the final assignment (:146-147): the training loop alone */
 int orc_kmeans_mini_batch(const float *X, size_t n, size_t d, size_t k,
                           size_t max_iters, float thr, uint64_t seed, int force_brute,
                           float *C, uint64_t *labels, uint64_t *iters_run);

@@ -166,21 +166,23 @@ def update_centroids(X, labels, k):
     return Cn, counts
 
 
-def _kmeans(fn, X, k, max_iters, thr, seed, force_brute):
+def _kmeans(fn, X, k, max_iters, thr, seed, force_brute, want_labels=True):
     X = f32c(X)
     if X.ndim != 2:
         X = X.reshape(0, 0)
     n, d = X.shape
     Cn = np.zeros((k, max(d, 1)), dtype=np.float32)[:, :d].copy()
-    labels = np.zeros(n, dtype=np.uint64)
+    labels = np.zeros(n, dtype=np.uint64) if want_labels else None
     iters = u64(0)
     rc = fn(_p(X), n, d, k, max_iters, -1.0 if thr is None else thr, seed, int(force_brute),
             _p(Cn), _p(labels), C.byref(iters))
     return rc, Cn, labels, iters.value
 
 
-def kmeans_mini_batch(X, k, max_iters, thr=None, seed=42, force_brute=False):
-    return _kmeans(lib().orc_kmeans_mini_batch, X, k, max_iters, thr, seed, force_brute)
+def kmeans_mini_batch(X, k, max_iters, thr=None, seed=42, force_brute=False, want_labels=True):
+    """want_labels=False: the training loop only (labels None) — for inputs whose final assignment the test checks on
+    sampled rows"""
+    return _kmeans(lib().orc_kmeans_mini_batch, X, k, max_iters, thr, seed, force_brute, want_labels)
 
 
 def kmeans_parallel(X, k, max_iters, thr=None, seed=42, force_brute=False):

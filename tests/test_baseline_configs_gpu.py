@@ -6,7 +6,13 @@ the CPU oracle on the same index files:
   C3  k-means exact assign N=1e6 x k=16384 x D=128 (the full-size centroid table; N bounded so that the oracle finishes):
       labels vs orc_assign_brute_force on every row the MFMA tiers left undecided + 20 000 sampled rows
 
-C4/C5 need an 8-GPU node; their per-rank code path is covered by test_search_gpu.py (striped ranks) and the gloo tests.
+  C3  the training loop itself at N=1e7 k=16384 D=128 (sampled k-means++ with 16 384 draws, 20 mini-batch iterations):
+      centroid bits vs orc_kmeans_mini_batch; final labels (reference 2-level mode and exact mode) on 20 000 sampled rows
+  C4  the C2 index loaded as 8 in-process ranks (one device) under BOTH partition rules, 1 000 queries, nprobe 16 / 32:
+      split coarse step + per-rank scan + packed merge == the oracle's single search (an 8-GPU node is not available to
+      the tests: the RCCL all-gather is replaced by the ranks writing side by side into one buffer)
+  C5  one rank's slice of N=1e8 D=96 nlist=65536 (N=1.25e7, X ~ N(0,1): real-valued => bf16 x 3 ranking, 65 536-row coarse
+      table): built by the product, 500 queries at nprobe 32 == the oracle on the same files
 """
 import ctypes as C
 import filecmp
@@ -67,6 +73,7 @@ def c2(tmp_path_factory):
     work = str(tmp_path_factory.mktemp("c2"))
     gpu = vip.build(xb, work, nlist=4096, now_secs=1_700_000_000)
     orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
+    gpu.work_dir = work
     return gpu, orc, xq[:1000].copy(), xq
 
 
@@ -175,3 +182,135 @@ def test_c3_exact_assign_k16384(monkeypatch):
         assert (hip.download(lab2, (rows.size,), np.uint32).astype(np.uint64) == want).all()
     finally:
         hip.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C4: the C2 index over 8 ranks, both partition rules (in-process: one device plays every rank)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("placement", [0, 1], ids=["stripes", "shard-placement"])
+def test_c4_eight_ranks_on_the_c2_index(c2, placement):
+    """src/ivf_index.rs:104-164 (lists -> shard files) decides what rank holds what under placement 1; stripes cut every
+    list by 64-vector blocks.  The multi-GPU protocol of bench.py --gpus 8: coarse step split by query
+    (vi_indexer_probe_device on each rank's slice), the probe lists side by side (the all-gather), every rank's scan of
+    the whole batch into its packed [D | I | tie] buffer (vi_indexer_search_probed_device), the packed merge — must return
+    the oracle's ids and distance bits (src/ivf_index.rs:190-267) at N=1e6, nlist=4096."""
+    gpu, orc, Q, _ = c2
+    world, d, k = 8, 128, 10
+    idx, sh = os.path.join(gpu.work_dir, "index"), os.path.join(gpu.work_dir, "shards")
+    parts = [vip.load(idx, sh, d, rank=r, world_size=world, placement=placement) for r in range(world)]
+    resident = [p.num_vectors for p in parts]
+    assert all(p.num_centroids == orc.num_centroids for p in parts)
+    if placement == 1:
+        assert sum(resident) == 1_000_000 and min(resident) > 0      # every vector on exactly one rank
+    else:
+        assert sum(resident) == 1_000_000 and max(resident) - min(resident) < 64 * orc.num_centroids
+    hip = Hip()
+    try:
+        nq = Q.shape[0]
+        xq = hip.upload(Q)
+        S = int(N.lib().vi_packed_result_bytes(nq, k))
+        off_i = (nq * k * 4 + 7) // 8 * 8
+        packed, Dm, Im = hip.alloc(world * S), hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+        per = (nq + world - 1) // world
+        for n_probe in (16, 32):
+            rc, Do, Io = orc.search_batch(Q, k, n_probe, O.usable_cpus())
+            assert rc == O.ORC_OK
+            probes, order = hip.alloc(nq * n_probe * 4), hip.alloc(nq * n_probe * 4)
+            for r, p in enumerate(parts):
+                q0, q1 = min(nq, r * per), min(nq, (r + 1) * per)
+                assert p.probe_device(xq + q0 * d * 4, q1 - q0, n_probe, probes + q0 * n_probe * 4,
+                                      order + q0 * n_probe * 4) == n_probe
+            for r, p in enumerate(parts):
+                b = packed + r * S
+                p.search_probed_device(xq, nq, k, n_probe, probes, order, b, b + off_i, b + off_i + nq * k * 8)
+            N.check(N.lib().vi_merge_partials_packed_device(0, nq, k, world, packed, Dm, Im))
+            assert_same(hip.download(Dm, (nq, k), np.float32), hip.download(Im, (nq, k), np.int64), Do, Io,
+                        f"C4 placement {placement} nprobe {n_probe}, split coarse + packed merge")
+            # the unsplit entry (every rank runs its own coarse step) and the three-array merge
+            Dg, Ig, Tg = hip.alloc(world * nq * k * 4), hip.alloc(world * nq * k * 8), hip.alloc(world * nq * k * 8)
+            for r, p in enumerate(parts):
+                p.search_device(xq, nq, k, n_probe, Dg + r * nq * k * 4, Ig + r * nq * k * 8, Tg + r * nq * k * 8)
+            N.check(N.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+            assert_same(hip.download(Dm, (nq, k), np.float32), hip.download(Im, (nq, k), np.int64), Do, Io,
+                        f"C4 placement {placement} nprobe {n_probe}, per-rank coarse")
+    finally:
+        hip.close()
+        del parts
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C3: the training loop at full size
+# ---------------------------------------------------------------------------------------------------------------
+def test_c3_mini_batch_train_n1e7_k16384():
+    """run_kmeans_mini_batch (src/kmeans.rs:64-150) at BASELINE C3: N=1e7 D=128 k=16384, max_iters=20
+    (calculate_max_iterations(1e7), utils.rs:18-26), batch 256: the sampled k-means++ branch (N > 50 000,
+    kmeans.rs:232-310: 16 384 draws over a 50 000-row sample), 20 full shuffles + mini-batch blends + re-seeds of the
+    clusters never hit.  Centroid bits must equal the oracle's; the final assignment (kmeans.rs:146-147 -> :445-581) is
+    checked on 20 000 sampled rows in the reference's 2-level mode and in exact mode (the oracle's own final pass over
+    1e7 rows would take minutes; the labels of a row depend on that row and the centroids only)."""
+    n, d, k, iters = 10_000_000, 128, 16384, 20
+    assert int(N.lib().vi_calculate_max_iterations(n)) == iters and int(N.lib().vi_minibatch_size(n)) == 256
+    rng = np.random.default_rng(42)
+    X = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 1_000_000):
+        X[s:s + 1_000_000] = rng.standard_normal((1_000_000, d), dtype=np.float32)
+    hip = Hip()
+    try:
+        Xd = hip.upload(X)
+        Cd, lab = hip.alloc(k * d * 4), hip.alloc(n * 4)
+        it = C.c_uint64(0)
+        N.check(N.lib().vi_kmeans_mini_batch_device(0, Xd, n, d, k, iters, -1.0, 42, N.VI_ASSIGN_REFERENCE, Cd, lab,
+                                                    C.byref(it)))
+        Cg = hip.download(Cd, (k, d), np.float32)
+        lab_ref = hip.download(lab, (n,), np.uint32)
+        rc, Co, _, it_o = O.kmeans_mini_batch(X, k, iters, None, 42, want_labels=False)
+        assert rc == O.ORC_OK and it.value == it_o
+        bad = np.nonzero((bits(Cg) != bits(Co)).any(axis=1))[0]
+        assert bad.size == 0, f"{bad.size} of {k} centroids differ from the oracle's, first {bad[0]}"
+        rows = np.unique(np.concatenate([rng.choice(n, 20_000, replace=False), [0, n - 1]]))
+        Xs = np.ascontiguousarray(X[rows])
+        want = O.assign(Xs, Co, seed=42, mode="hier")
+        got = lab_ref[rows].astype(np.uint64)
+        assert (got == want).all(), f"{(got != want).sum()} of {rows.size} reference-mode labels differ"
+        # exact mode: same training loop (same centroids), final assignment == brute force
+        N.check(N.lib().vi_kmeans_mini_batch_device(0, Xd, n, d, k, iters, -1.0, 42, N.VI_ASSIGN_EXACT, Cd, lab, None))
+        assert (bits(hip.download(Cd, (k, d), np.float32)) == bits(Co)).all()
+        want = O.assign(Xs, Co, mode="brute")
+        got = hip.download(lab, (n,), np.uint32)[rows].astype(np.uint64)
+        assert (got == want).all(), f"{(got != want).sum()} of {rows.size} exact-mode labels differ"
+    finally:
+        hip.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C5: one rank's slice (1/8 of N=1e8) at the full list count
+# ---------------------------------------------------------------------------------------------------------------
+def test_c5_per_rank_slice_n12_5m_d96_nlist65536(tmp_path_factory):
+    """BASELINE C5 = N=1e8 D=96 nlist=65536 over 8 GPUs; one rank holds N/8 = 1.25e7 vectors.  X ~ N(0,1): real-valued
+    lists => the bf16 x 3 ranking arithmetic, a 65 536-row coarse table on the MFMA coarse path.  The product builds the
+    index (GPU k-means, GPU list build, shard export), the oracle loads the very same files, and 500 queries at
+    nprobe 32 (+ 100 at nprobe 8 and 64) must return its ids and distance bits (src/ivf_index.rs:190-267)."""
+    n, d, nlist, k = 12_500_000, 96, 65536, 10
+    rng = np.random.default_rng(42)
+    xb = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 1_250_000):
+        xb[s:s + 1_250_000] = rng.standard_normal((1_250_000, d), dtype=np.float32)
+    xq = rng.standard_normal((500, d), dtype=np.float32)
+    work = str(tmp_path_factory.mktemp("c5"))
+    gpu = vip.build(xb, work, nlist=nlist, now_secs=1_700_000_000)
+    del xb
+    try:
+        bs = gpu.build_stats()
+        assert gpu.num_vectors == n and bs["nlist"] == nlist and bs["shards"] == 256
+        orc = O.OracleIndex.load(os.path.join(work, "index"), os.path.join(work, "shards"))
+        assert orc.num_centroids == gpu.num_centroids and orc.num_shards <= 256
+        for n_probe, nq in ((32, 500), (8, 100), (64, 100)):
+            rc, Do, Io = orc.search_batch(xq[:nq], k, n_probe, O.usable_cpus())
+            assert rc == O.ORC_OK
+            Dg, Ig = gpu.search_sync(xq[:nq], k, n_probe)
+            st = gpu.last_stats()
+            assert st["rank_mode"] == 2, st                       # bf16 x 3 on the matrix cores, not a fallback
+            assert_same(Dg, Ig, Do, Io, f"C5 slice nprobe {n_probe}")
+    finally:
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
