@@ -459,7 +459,7 @@ def main():
         ub = 4.0 * n3 * d3 + 8.0 * n3 + 4.0 * k3 * d3
         kmeans["update_pass"] = {"ms": round(min(tu) * 1e3, 2), "algorithmic_GBps": round(ub / min(tu) / 1e9, 1),
                                  "frac_of_hbm_peak": round(ub / min(tu) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "note": "vi_kmeans_partial_sums_device: grouping of the ids by cluster (device bitonic sort) + "
+                                 "note": "vi_kmeans_partial_sums_device: grouping of the ids by cluster (stable device radix sort) + "
                                          "sums in ascending id order (the reference's order), whole call"}
         del sums, cnts, lab
         # reference-compat mini-batch train (B=256, 20 iterations + final assign), device-resident points

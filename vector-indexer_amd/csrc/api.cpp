@@ -109,7 +109,8 @@ static vi_status fit_and_save(Indexer *ix, const float *X, const uint64_t *ext_i
   bs.ms_kmeans = (float)(t2 - t1);
   // IVF lists in ascending internal id (:94-101): ids grouped by label on the device
   std::vector<uint64_t> off;
-  VI_TRY(group_ids_by_label_device(lab.p, n, k, order, off, st));
+  DevBuf<uint32_t> seg_dev;
+  VI_TRY(group_ids_by_label_device(lab.p, n, k, order, seg_dev, &off, st));
   const double t3 = now_ms();
   bs.ms_group = (float)(t3 - t2);
   // super-centroids => shard of every list (:104-109)

@@ -166,9 +166,12 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
                                  const std::vector<uint32_t> *list_shard, DeviceIndex *out);
 
 // ---- GPU list build (list_build.hip) ----
-// ids 0..n-1 grouped by label, ascending id inside a label: order (device, n u32) and off[k+1] (host)
+// ids 0..n-1 grouped by label, ascending id inside a label (stable radix sort): order (device, n u32), seg (device,
+// k+1 u32 offsets into order) and the offsets on the host if off_host is given.  Complete on return.  scratch_keep
+// (optional): the sort's scratch (3 n + 256 n / 4096 words) in a buffer of the caller's, kept from call to call.
 vi_status group_ids_by_label_device(const uint32_t *labels_dev, uint64_t n, uint64_t k, DevBuf<uint32_t> &order,
-                                    std::vector<uint64_t> &off, hipStream_t st);
+                                    DevBuf<uint32_t> &seg, std::vector<uint64_t> *off_host, hipStream_t st,
+                                    DevBuf<uint32_t> *scratch_keep = nullptr);
 // resident index straight from device data: list l = rows order[src_off[l] .. + len[l]) of X_dev
 vi_status device_index_from_order(int device, uint32_t dim, const float *table_host, uint64_t nlists, const float *X_dev,
                                   const uint32_t *order_dev, const std::vector<uint64_t> &src_off,

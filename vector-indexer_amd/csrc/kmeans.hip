@@ -8,9 +8,8 @@
 // Split of work:
 //   GPU  every distance (exact lane-structured order of compute_distance_simd, kmeans.rs:377-419),
 //        every arg-min, every centroid sum / mean / blend, the RMS delta partials
-//   host the rand-0.8.5 stream (rng.hpp) and the decisions drawn from it, stable grouping of
-//        point ids by label (index bookkeeping), and the strictly sequential f32 prefix sum of
-//        WeightedIndex (inherently serial; it consumes distances produced on the GPU)
+//   host the rand-0.8.5 stream (rng.hpp) and the decisions drawn from it, and the strictly sequential
+//        f32 prefix sum of WeightedIndex (inherently serial; it consumes distances produced on the GPU)
 //
 // assign_points_hierarchical (k > 100) is literally a 2-level IVF search of the centroid
 // table: coarse = meta-centroids (top-3, stable order), lists = centroids grouped by
@@ -21,7 +20,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <cstdio>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "assign_mfma.hpp"
@@ -72,19 +74,227 @@ __global__ void min_dist_update_kernel(const float *X, uint32_t m, uint32_t d, c
   if (dist < min_d[i]) min_d[i] = dist;
 }
 
-// per-cluster mean with the sum taken in ascending member order (kmeans.rs:693-703).
-// one thread per (cluster, dim); keep_old: leave the row untouched when the cluster is empty
-// (build_centroid_hierarchy, kmeans.rs:634-638) instead of writing zeros.
-__global__ void segment_mean_kernel(const float *X, const uint32_t *order, const uint32_t *seg_off, uint32_t k,
-                                    uint32_t d, float *C, int keep_old) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (uint64_t)k * d) return;
-  const uint32_t c = (uint32_t)(t / d), j = (uint32_t)(t % d);
-  const uint32_t b = seg_off[c], e = seg_off[c + 1];
+// sum over the members order[b..e) of X[member, j], added strictly in that order (the reference's sequential f32 sum,
+// kmeans.rs:693-697).  The chain of adds is short (4 cycles each); what a big cluster costs is the latency of its row
+// loads — so 32 rows are requested ahead of the 32 being added (the member ids are wave-uniform: scalar loads).
+constexpr int kSegAhead = 32;
+__device__ __forceinline__ float segment_sum_ordered(const float *__restrict__ X, const uint32_t *__restrict__ order,
+                                                     uint32_t b, uint32_t e, uint32_t d, uint32_t j) {
   float sum = 0.0f;
-  for (uint32_t i = b; i < e; ++i) sum += X[(size_t)order[i] * d + j];
-  if (e > b) C[t] = sum / (float)(e - b);
-  else if (!keep_old) C[t] = 0.0f;
+  float cur[kSegAhead], nxt[kSegAhead];
+#pragma unroll
+  for (int u = 0; u < kSegAhead; ++u) cur[u] = b + u < e ? X[(size_t)order[b + u] * d + j] : 0.0f;
+  for (uint32_t i = b; i < e; i += kSegAhead) {
+    const uint32_t i2 = i + kSegAhead;
+#pragma unroll
+    for (int u = 0; u < kSegAhead; ++u) nxt[u] = i2 + u < e ? X[(size_t)order[i2 + u] * d + j] : 0.0f;
+    if (i2 <= e) {
+#pragma unroll
+      for (int u = 0; u < kSegAhead; ++u) sum += cur[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < kSegAhead; ++u) if (i + u < e) sum += cur[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kSegAhead; ++u) cur[u] = nxt[u];
+  }
+  return sum;
+}
+
+// What a cluster's sum becomes: kSegSums = the sum itself and the member count (per-rank partial of the data-parallel
+// update), kSegMean = sum / count with zeros for an empty cluster (update_centroids_parallel, kmeans.rs:699-712),
+// kSegMeanKeep = the same but an empty cluster keeps its row (build_centroid_hierarchy, kmeans.rs:634-638).
+enum SegMode : int { kSegSums = 0, kSegMean = 1, kSegMeanKeep = 2 };
+
+__device__ __forceinline__ void segment_store(int mode, float sum, uint32_t members, float *out) {
+  if (mode == kSegSums) *out = sum;
+  else if (members) *out = sum / (float)members;
+  else if (mode == kSegMean) *out = 0.0f;
+}
+
+// one workgroup per cluster, threads over the dimensions; clusters above skip_above members are left to
+// segment_big_kernel
+__global__ void segment_kernel(const float *__restrict__ X, const uint32_t *__restrict__ order,
+                               const uint32_t *__restrict__ seg_off, uint32_t k, uint32_t d, float *out, uint32_t *counts,
+                               int mode, uint32_t skip_above) {
+  const uint32_t c = blockIdx.x;
+  if (c >= k) return;
+  const uint32_t b = seg_off[c], e = seg_off[c + 1];
+  if (e - b > skip_above) return;
+  for (uint32_t j = threadIdx.x; j < d; j += blockDim.x)
+    segment_store(mode, e > b ? segment_sum_ordered(X, order, b, e, d, j) : 0.0f, e - b, out + (size_t)c * d + j);
+  if (counts && threadIdx.x == 0) counts[c] = e - b;
+}
+
+// A few clusters hold a large share of the points (C3: 446 of 16 384 hold 43 %, the largest 57 744) and the sum of one
+// cluster is a sequential chain: with one or two waves per cluster the pass ends in a long tail of single waves waiting
+// on their row loads.  Clusters above kBigCluster members are therefore summed by a whole 512-thread workgroup: all 8
+// waves fetch the rows of the next chunk (kBigChunkFloats / d rows, 64 KB) while the first d threads add the staged
+// chunk from LDS in member order — the order of the adds is unchanged, only who waits for memory.
+constexpr uint32_t kBigCluster = 2048, kBigThreads = 512, kBigChunkFloats = 16384, kBigMaxDim = 512;
+constexpr int kBigLoads = kBigChunkFloats / 4 / kBigThreads;  // 16-byte row pieces a thread requests per chunk
+
+__global__ void segment_big_list_kernel(const uint32_t *seg_off, uint32_t k, uint32_t *nbig, uint32_t *list) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < k && seg_off[c + 1] - seg_off[c] > kBigCluster) list[atomicAdd(nbig, 1u)] = c;  // (any order: one block each)
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));  // (arrays of HIP's float4 struct stay in scratch memory)
+
+__global__ void __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) segment_big_kernel(const float *__restrict__ X, const uint32_t *__restrict__ order,
+                                                                  const uint32_t *__restrict__ seg_off,
+                                                                  const uint32_t *__restrict__ nbig_ptr,
+                                                                  const uint32_t *__restrict__ list, uint32_t d, float *out,
+                                                                  uint32_t *counts, int mode) {
+  extern __shared__ vf4 ring4[];  // two halves of kBigChunkFloats (H rows x d floats, rounded up)
+  const uint32_t dq = d / 4;         // (d % 4 == 0: rows are read as 16-byte pieces — one instruction moves 1 KB; with
+                                     //  4-byte pieces the CU's vector-memory issue rate, not HBM, set the pace: 3.3 us a chunk)
+  const uint32_t H = kBigChunkFloats / d, t = threadIdx.x;
+  const uint32_t nbig = *nbig_ptr;
+  const uint32_t step_row = kBigThreads / dq, step_col = kBigThreads % dq, row0 = t / dq, col0 = t % dq;
+  float *ring = reinterpret_cast<float *>(ring4);
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const uint32_t c = list[bi], b = seg_off[c], e = seg_off[c + 1];
+    // Rows r0 .. r0 + H of the cluster into a register set, in two steps a pipeline stage apart: the member ids, then
+    // the rows they name.  Piece t + p * 512 of a chunk is (row, col) = divmod(., d / 4), stepped without dividing.
+    // No predication: a row past the cluster's end is clamped to its last member (staged but never added), so the
+    // loads of either step are issued back to back (as conditional loads the compiler emitted dependent round trips).
+    // (macros, not lambdas over array references: those left the register sets in scratch memory)
+#define VI_FETCH_IDS(id, r0_)                                        \
+    {                                                                \
+      uint32_t row_ = row0, cl_ = col0;                              \
+      _Pragma("unroll") for (int p = 0; p < kBigLoads; ++p) {        \
+        id[p] = order[min((r0_) + row_, e - 1)];                     \
+        row_ += step_row; cl_ += step_col;                           \
+        if (cl_ >= dq) { cl_ -= dq; ++row_; }                        \
+      }                                                              \
+    }
+#define VI_FETCH_ROWS(regs, id)                                      \
+    {                                                                \
+      uint32_t cl_ = col0;                                           \
+      _Pragma("unroll") for (int p = 0; p < kBigLoads; ++p) {        \
+        regs[p] = reinterpret_cast<const vf4 *>(X + (size_t)id[p] * d)[cl_]; \
+        cl_ += step_col;                                             \
+        if (cl_ >= dq) cl_ -= dq;                                    \
+      }                                                              \
+    }
+    // (a half has room for all 4096 pieces)
+#define VI_STAGE(half, regs) \
+    { _Pragma("unroll") for (int p = 0; p < kBigLoads; ++p) (half)[t + p * kBigThreads] = regs[p]; }
+    float sum = 0.0f;
+    auto add_chunk = [&](const float *half, uint32_t r0) {  // the staged rows r0 .. r0 + H, in member order
+      if (t >= d) return;
+      half += t;
+      const uint32_t rows = r0 < e ? min(H, e - r0) : 0u;
+      uint32_t r = 0;
+      for (; r + 16 <= rows; r += 16) {  // 16 LDS reads in flight, then the 16 adds
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = half[(r + u) * d];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += v[u];
+      }
+      for (; r < rows; ++r) sum += half[r * d];
+    };
+    // Three register sets rotate: while chunk n is added from LDS, chunk n+1 is copied from its set into the other half
+    // and chunks n+2, n+3 are in flight.
+    vf4 ra[kBigLoads], rb[kBigLoads], rc[kBigLoads];
+    uint32_t idq[kBigLoads];  // ids of the chunk whose rows are requested next
+    VI_FETCH_IDS(idq, b)
+    VI_FETCH_ROWS(ra, idq)
+    VI_FETCH_IDS(idq, b + H)
+    VI_FETCH_ROWS(rb, idq)
+    VI_FETCH_IDS(idq, b + 2 * H)
+    VI_FETCH_ROWS(rc, idq)
+    VI_FETCH_IDS(idq, b + 3 * H)
+    VI_STAGE(ring4, ra)
+    __syncthreads();
+    uint32_t r0 = b, cur = 0;
+    // one step: ring[cur] holds chunk r0, `nxt` holds chunk r0 + H, `free` is refilled with chunk r0 + 3H (its ids
+    // were requested a step ago), the ids of chunk r0 + 4H are requested
+    // (straight-line code, three steps per trip, no condition inside a step: with `if (r0 < e)` around each step the
+    //  compiler rotated the sets by copies and waited for every load right after issuing it.  Steps past the end add
+    //  nothing and fetch the clamped last row.)
+#define VI_BIG_STEP(nxt, free)                         \
+    {                                                  \
+      add_chunk(ring + cur * kBigChunkFloats, r0);     \
+      VI_FETCH_ROWS(free, idq)                         \
+      VI_FETCH_IDS(idq, r0 + 4 * H)                    \
+      VI_STAGE(ring4 + (cur ^ 1u) * (kBigChunkFloats / 4), nxt) \
+      __syncthreads();                                 \
+      cur ^= 1u; r0 += H;                              \
+    }
+    while (r0 < e) {
+      VI_BIG_STEP(rb, ra)
+      VI_BIG_STEP(rc, rb)
+      VI_BIG_STEP(ra, rc)
+    }
+#undef VI_BIG_STEP
+#undef VI_FETCH_IDS
+#undef VI_FETCH_ROWS
+#undef VI_STAGE
+    if (t < d) segment_store(mode, sum, e - b, out + (size_t)c * d + t);
+    if (counts && t == 0) counts[c] = e - b;
+  }
+}
+
+struct SegWs {
+  DevBuf<uint32_t> big;  // [0] = number of big clusters, then their ids
+};
+
+// Everything an update pass allocates (ids grouped by cluster, offsets, the sort's scratch, the big-cluster list): 16 n
+// bytes.  A Lloyd loop keeps one across its iterations; the one-pass entry point (vi_kmeans_partial_sums_device) borrows
+// one from a process-wide pool, so that a caller's training loop does not pay five allocations and releases (1.5 ms —
+// as long as the pass itself at C3) per call.  Pooled workspaces are never freed (16 n bytes of 288 GB stay reserved).
+struct UpdateWs {
+  int device = -1;
+  DevBuf<uint32_t> order, seg, scratch, bad;
+  SegWs seg_ws;
+};
+struct UpdateWsPool {
+  std::mutex m;
+  std::vector<UpdateWs *> idle;
+  UpdateWs *acquire(int device) {
+    std::lock_guard<std::mutex> g(m);
+    for (size_t i = 0; i < idle.size(); ++i)
+      if (idle[i]->device == device) { UpdateWs *w = idle[i]; idle.erase(idle.begin() + i); return w; }
+    UpdateWs *w = new UpdateWs;
+    w->device = device;
+    return w;
+  }
+  void release(UpdateWs *w) { std::lock_guard<std::mutex> g(m); idle.push_back(w); }
+};
+UpdateWsPool &update_ws_pool() {
+  static UpdateWsPool *pool = new UpdateWsPool;  // (never destroyed: no hipFree after the runtime has shut down)
+  return *pool;
+}
+struct UpdateWsLease {
+  UpdateWs *ws;
+  explicit UpdateWsLease(int device) : ws(update_ws_pool().acquire(device)) {}
+  ~UpdateWsLease() { update_ws_pool().release(ws); }
+};
+
+// sums / means of all k clusters from the grouped ids (order, seg_off); the work is queued on st
+vi_status launch_segment_sums(const float *X, const uint32_t *order, const uint32_t *seg_off, uint64_t k, uint32_t d,
+                              float *out, uint32_t *counts, SegMode mode, SegWs &ws, hipStream_t st) {
+  const uint32_t threads = std::min<uint32_t>(256u, (d + 63u) & ~63u);
+  const bool split = d <= kBigMaxDim && d >= 16 && d % 4 == 0 && ((uintptr_t)X & 15) == 0;
+  if (split) {
+    VI_TRY(ws.big.reserve(k + 1));
+    VI_HIP(hipMemsetAsync(ws.big.p, 0, 4, st));
+    hipLaunchKernelGGL(segment_big_list_kernel, dim3((uint32_t)((k + 255) / 256)), dim3(256), 0, st, seg_off, (uint32_t)k,
+                       ws.big.p, ws.big.p + 1);
+  }
+  hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)k), dim3(threads), 0, st, X, order, seg_off, (uint32_t)k, d, out, counts,
+                     (int)mode, split ? kBigCluster : 0xFFFFFFFFu);
+  if (split) {
+    const size_t lds = 2ull * kBigChunkFloats * sizeof(float);
+    VI_HIP(hipFuncSetAttribute((const void *)segment_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(segment_big_kernel, dim3((uint32_t)std::min<uint64_t>(k, 1024)), dim3(kBigThreads), lds, st, X, order,
+                       seg_off, ws.big.p, ws.big.p + 1, d, out, counts, (int)mode);
+  }
+  VI_HIP(hipGetLastError());
+  return VI_OK;
 }
 
 // update_centroids_mini_batch (kmeans.rs:729-787) for the clusters touched by this batch
@@ -141,6 +351,35 @@ __global__ void i64_to_u32_kernel(const int64_t *in, uint64_t n, uint32_t *out) 
   if (i < n) out[i] = in[i] < 0 ? 0u : (uint32_t)in[i];
 }
 
+// ChaCha12 keystream in bulk (rand_chacha 0.3.1 as rng.hpp restates it): thread = one 16-word block of counter
+// first + t.  sample_batch's full shuffle (kmeans.rs:722-726) reads ~1.7 n words per iteration; the host only walks them.
+__global__ void chacha12_blocks_kernel(const uint32_t k0, const uint32_t k1, const uint32_t k2, const uint32_t k3,
+                                       const uint32_t k4, const uint32_t k5, const uint32_t k6, const uint32_t k7,
+                                       uint64_t first, uint64_t nblocks, uint32_t *out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nblocks) return;
+  const uint64_t ctr = first + t;
+  const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, k0, k1, k2, k3, k4, k5, k6, k7,
+                          (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = s[i];
+#define VI_QR(a, b, c, d)                                                     \
+  x[a] += x[b]; x[d] ^= x[a]; x[d] = (x[d] << 16) | (x[d] >> 16);             \
+  x[c] += x[d]; x[b] ^= x[c]; x[b] = (x[b] << 12) | (x[b] >> 20);             \
+  x[a] += x[b]; x[d] ^= x[a]; x[d] = (x[d] << 8) | (x[d] >> 24);              \
+  x[c] += x[d]; x[b] ^= x[c]; x[b] = (x[b] << 7) | (x[b] >> 25);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    VI_QR(0, 4, 8, 12) VI_QR(1, 5, 9, 13) VI_QR(2, 6, 10, 14) VI_QR(3, 7, 11, 15)
+    VI_QR(0, 5, 10, 15) VI_QR(1, 6, 11, 12) VI_QR(2, 7, 8, 13) VI_QR(3, 4, 9, 14)
+  }
+#undef VI_QR
+  uint4 *dst = reinterpret_cast<uint4 *>(out + t * 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i] = make_uint4(x[4 * i] + s[4 * i], x[4 * i + 1] + s[4 * i + 1], x[4 * i + 2] + s[4 * i + 2], x[4 * i + 3] + s[4 * i + 3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // device context
 // ------------------------------------------------------------------------------------------
@@ -159,6 +398,43 @@ struct Ctx {
     return VI_OK;
   }
 };
+
+// KeystreamSource (rng.hpp) on the device: blocks generated into HBM, one copy into pinned host memory
+struct GpuKeystream : KeystreamSource {
+  hipStream_t st;
+  DevBuf<uint32_t> dev;
+  uint32_t *host = nullptr;
+  uint64_t host_cap = 0;
+  explicit GpuKeystream(hipStream_t s) : st(s) {}
+  ~GpuKeystream() override { if (host) (void)hipHostFree(host); }
+  const uint32_t *blocks(const uint32_t key[8], uint64_t first_block, uint64_t nblocks) override {
+    const uint64_t words = nblocks * 16;
+    if (dev.reserve(words) != VI_OK) return nullptr;
+    if (host_cap < words) {
+      if (host) (void)hipHostFree(host);
+      host = nullptr; host_cap = 0;
+      if (hipHostMalloc((void **)&host, words * 4) != hipSuccess) return nullptr;
+      host_cap = words;
+    }
+    hipLaunchKernelGGL(chacha12_blocks_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, st, key[0], key[1],
+                       key[2], key[3], key[4], key[5], key[6], key[7], first_block, nblocks, dev.p);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(host, dev.p, words * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    return host;
+  }
+};
+
+// VI_KMEANS_TIMING=1: phase times of the training loops on stderr
+bool kmeans_timing() {
+  static const bool on = [] { const char *e = getenv("VI_KMEANS_TIMING"); return e && *e == '1'; }();
+  return on;
+}
+double wall_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 template <typename T>
 vi_status to_device(DevBuf<T> &buf, const T *host, size_t n, hipStream_t st) {
@@ -290,6 +566,7 @@ vi_status assign_hier_device(Ctx &cx, const float *Xd, uint64_t n, const float *
   VI_TRY(d_c2m.reserve(k));
   std::vector<uint32_t> c2m(k), order, seg;
   BruteWs bws;
+  SegWs sws;
   for (int iter = 0; iter < 5; ++iter) {
     VI_TRY(assign_brute_device(cx, Cd, k, meta.p, meta_k, d, d_c2m.p, nullptr, bws));
     VI_HIP(hipMemcpyAsync(c2m.data(), d_c2m.p, k * 4, hipMemcpyDeviceToHost, cx.st));
@@ -297,10 +574,7 @@ vi_status assign_hier_device(Ctx &cx, const float *Xd, uint64_t n, const float *
     group_by_label(c2m.data(), k, meta_k, order, seg);
     VI_TRY(to_device(d_order, order.data(), order.size(), cx.st));
     VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
-    const uint64_t nt = meta_k * d;
-    hipLaunchKernelGGL(segment_mean_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Cd, d_order.p,
-                       d_seg.p, (uint32_t)meta_k, d, meta.p, 1);
-    VI_HIP(hipGetLastError());
+    VI_TRY(launch_segment_sums(Cd, d_order.p, d_seg.p, meta_k, d, meta.p, nullptr, kSegMeanKeep, sws, cx.st));
     VI_HIP(hipStreamSynchronize(cx.st));
   }
   // two-level index: coarse = meta-centroids, list m = centroids of meta cluster m, ascending c
@@ -416,7 +690,8 @@ vi_status kmeans_pp_init_rows(Ctx &cx, RowSource &src, uint64_t n, uint32_t d, u
   std::vector<uint32_t> csel(k, 0);  // every initial centroid is a copy of a row of `cand`
   DevBuf<float> min_d;
   VI_TRY(min_d.reserve(m));
-  std::vector<float> h_min(m, INFINITY), w(m), cum(m);
+  std::vector<float> h_min(m, INFINITY), cum(m);
+  const double t_pp0 = wall_ms();
   VI_HIP(hipMemcpyAsync(min_d.p, h_min.data(), m * 4, hipMemcpyHostToDevice, cx.st));
   float *pinned = nullptr;
   VI_HIP(hipHostMalloc((void **)&pinned, std::max<uint64_t>(m, 1) * sizeof(float)));
@@ -429,11 +704,14 @@ vi_status kmeans_pp_init_rows(Ctx &cx, RowSource &src, uint64_t n, uint32_t d, u
       rc = fail(VI_ERR_DEVICE, "k-means++ distance pass failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }
-    float total = 0.0f;
-    for (uint64_t j = 0; j < m; ++j) { w[j] = pinned[j] * pinned[j]; total += w[j]; }  // :190,193 (dist^4, sequential)
+    // weights = dist^4 (:190), their sum (:193) and WeightedIndex's cumulative weights are ONE left-to-right chain
+    // (0 + w0 = w0 exactly): cum[j] = w0 + .. + wj
+    float total = pinned[0] * pinned[0];
+    for (uint64_t j = 1; j < m; ++j) { cum[j - 1] = total; total += pinned[j] * pinned[j]; }
     if (total == 0.0f) csel[i] = csel[rng.gen_range(0, i)];
-    else csel[i] = (uint32_t)rng.weighted_index(w.data(), m, cum.data()) + 1u;
+    else csel[i] = (uint32_t)rng.weighted_index_cum(cum.data(), total, m) + 1u;
   }
+  if (kmeans_timing()) fprintf(stderr, "[vi kmeans] k-means++ %llu draws over %llu rows: %.1f ms\n", (unsigned long long)actual_k, (unsigned long long)m, wall_ms() - t_pp0);
   (void)hipHostFree(pinned);
   VI_TRY(rc);
   for (uint64_t i = actual_k; i < k; ++i) csel[i] = csel[rng.gen_range(0, actual_k)];
@@ -552,20 +830,6 @@ vi_status assign_points_device(int device, const float *Xd, uint64_t n, uint32_t
 // ------------------------------------------------------------------------------------------
 // per-rank pieces of the data-parallel Lloyd update (update_centroids_parallel, kmeans.rs:674-719)
 // ------------------------------------------------------------------------------------------
-// sums[c, j] = sum of X[i, j] over this rank's members of cluster c in ascending i (the reference's order inside
-// the rank), counts[c] = members.  One thread per (cluster, dim) over the stable grouping of the rank's points.
-__global__ void segment_sum_kernel(const float *X, const uint32_t *order, const uint32_t *seg_off, uint32_t k,
-                                   uint32_t d, float *sums, uint32_t *counts) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (uint64_t)k * d) return;
-  const uint32_t c = (uint32_t)(t / d), j = (uint32_t)(t % d);
-  const uint32_t b = seg_off[c], e = seg_off[c + 1];
-  float sum = 0.0f;
-  for (uint32_t i = b; i < e; ++i) sum += X[(size_t)order[i] * d + j];
-  sums[t] = sum;
-  if (j == 0) counts[c] = e - b;
-}
-
 __global__ void label_range_kernel(const uint32_t *labels, uint64_t n, uint32_t k, uint32_t *bad) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && labels[i] >= k) atomicOr(bad, 1u);
@@ -596,28 +860,20 @@ vi_status lloyd_core(Ctx &cx, const float *Xd, uint64_t n, uint32_t d, uint64_t 
   StdRng rng(seed);
   DeviceRows src(Xd, d);
   DevBuf<float> Cn, local, rowbuf;
-  DevBuf<uint32_t> d_order, d_seg;
+  UpdateWs uws;
   VI_TRY(Cn.reserve(k * d));
   VI_HIP(hipMemsetAsync(lab, 0, n * 4, cx.st));
   VI_TRY(kmeans_pp_init_rows(cx, src, n, d, k, seed, Cd));
   BruteWs bws;
-  std::vector<uint32_t> l32(n), order, seg;
-  std::vector<uint64_t> counts(k);
+  std::vector<uint64_t> counts(k), off;
   std::vector<float> h_local;
   uint64_t it = 0;
   for (; it < max_iters; ++it) {
     VI_TRY(assign_device(cx, Xd, n, Cd, k, d, seed, mode, lab, bws));
-    VI_HIP(hipMemcpyAsync(l32.data(), lab, n * 4, hipMemcpyDeviceToHost, cx.st));
-    VI_HIP(hipStreamSynchronize(cx.st));
-    group_by_label(l32.data(), n, k, order, seg);
-    VI_TRY(to_device(d_order, order.data(), order.size(), cx.st));
-    VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
-    const uint64_t nt = k * d;
-    hipLaunchKernelGGL(segment_mean_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd, d_order.p,
-                       d_seg.p, (uint32_t)k, d, Cn.p, 0);
-    VI_HIP(hipGetLastError());
-    VI_HIP(hipStreamSynchronize(cx.st));
-    for (uint64_t c = 0; c < k; ++c) counts[c] = seg[c + 1] - seg[c];
+    // members of every cluster in ascending id (kmeans.rs:688-697), grouped on the device (list_build.hip)
+    VI_TRY(group_ids_by_label_device(lab, n, k, uws.order, uws.seg, &off, cx.st, &uws.scratch));
+    VI_TRY(launch_segment_sums(Xd, uws.order.p, uws.seg.p, k, d, Cn.p, nullptr, kSegMean, uws.seg_ws, cx.st));
+    for (uint64_t c = 0; c < k; ++c) counts[c] = off[c + 1] - off[c];
     VI_TRY(handle_empty_rows(cx, src, n, d, counts, rng, Cn.p, rowbuf));
     float delta = 0.0f;
     VI_TRY(centroid_delta_device(cx, Cn.p, Cd, k, d, local, h_local, &delta));
@@ -643,16 +899,23 @@ vi_status mini_batch_train_core(Ctx &cx, RowSource &src, uint64_t n, uint32_t d,
   VI_TRY(kmeans_pp_init_rows(cx, src, n, d, k, seed, Cd));
   VI_HIP(hipMemcpyAsync(prev.p, Cd, k * d * 4, hipMemcpyDeviceToDevice, cx.st));
   std::vector<uint64_t> counts(k, 0);
-  std::vector<uint32_t> perm(n), bidx(B), blab(B), members, tc, ts, tl;
+  std::vector<uint32_t> bidx(B), blab(B), members, tc, ts, tl, draws;
+  std::vector<uint64_t> follow_bits;
+  GpuKeystream gks(cx.st);
+  double t_shuffle = 0.0;
+  const double t_loop0 = wall_ms();
   std::vector<float> teta, h_local;
   std::vector<uint32_t> head(k), nxt(B);
   BruteWs bws;
   uint64_t it = 0;
   for (; it < max_iters; ++it) {
-    // sample_batch (kmeans.rs:722-726): full shuffle of 0..n, first B
-    for (uint64_t i = 0; i < n; ++i) perm[i] = (uint32_t)i;
-    rng.shuffle(perm.data(), n);
-    std::copy(perm.begin(), perm.begin() + B, bidx.begin());
+    // sample_batch (kmeans.rs:722-726): full shuffle of 0..n, first B — only those B entries are formed (rng.hpp)
+    const double t_s0 = wall_ms();
+    if (!rng.shuffle_head(n, B, bidx.data(), gks, draws, follow_bits)) {
+      HostKeystream hks;
+      if (!rng.shuffle_head(n, B, bidx.data(), hks, draws, follow_bits)) return fail(VI_ERR_OTHER, "sample_batch failed");
+    }
+    t_shuffle += wall_ms() - t_s0;
     VI_TRY(src.fetch(bidx.data(), B, Qb.p, cx.st));
     // batch assignment is always brute force over all k (kmeans.rs:103-110)
     VI_TRY(assign_exact_device(cx, Qb.p, B, Cd, k, d, d_blab.p, bws));
@@ -697,6 +960,7 @@ vi_status mini_batch_train_core(Ctx &cx, RowSource &src, uint64_t n, uint32_t d,
   }
   if (iters_run) *iters_run = it;
   VI_HIP(hipStreamSynchronize(cx.st));
+  if (kmeans_timing()) fprintf(stderr, "[vi kmeans] mini-batch loop %llu iterations: %.1f ms, of which sample_batch %.1f ms\n", (unsigned long long)it, wall_ms() - t_loop0, t_shuffle);
   return VI_OK;
 }
 
@@ -809,25 +1073,20 @@ vi_status kmeans_partial_sums_device(int device, const float *Xd, uint64_t n, ui
   Ctx cx;
   VI_TRY(cx.init(device));
   // ids grouped by cluster, ascending id inside a cluster, without leaving the device (list_build.hip)
-  DevBuf<uint32_t> d_order, d_seg, d_bad;
-  std::vector<uint64_t> off;
-  VI_TRY(d_bad.reserve(1));
-  VI_HIP(hipMemsetAsync(d_bad.p, 0, 4, cx.st));
+  UpdateWsLease lease(device);
+  UpdateWs &w = *lease.ws;
+  VI_TRY(w.bad.reserve(1));
+  VI_HIP(hipMemsetAsync(w.bad.p, 0, 4, cx.st));
   if (n) {
-    hipLaunchKernelGGL(label_range_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, cx.st, labels_dev, n, (uint32_t)k, d_bad.p);
+    hipLaunchKernelGGL(label_range_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, cx.st, labels_dev, n, (uint32_t)k, w.bad.p);
     VI_HIP(hipGetLastError());
   }
   uint32_t bad = 0;
-  VI_HIP(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, cx.st));
+  VI_HIP(hipMemcpyAsync(&bad, w.bad.p, 4, hipMemcpyDeviceToHost, cx.st));
   VI_HIP(hipStreamSynchronize(cx.st));
   if (bad) return fail(VI_ERR_INVALID_INPUT, "a label is not below k");
-  VI_TRY(group_ids_by_label_device(labels_dev, n, k, d_order, off, cx.st));
-  std::vector<uint32_t> seg(off.begin(), off.end());
-  VI_TRY(to_device(d_seg, seg.data(), seg.size(), cx.st));
-  const uint64_t nt = k * d;
-  hipLaunchKernelGGL(segment_sum_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, cx.st, Xd, d_order.p, d_seg.p,
-                     (uint32_t)k, d, sums_dev, counts_dev);
-  VI_HIP(hipGetLastError());
+  VI_TRY(group_ids_by_label_device(labels_dev, n, k, w.order, w.seg, nullptr, cx.st, &w.scratch));
+  VI_TRY(launch_segment_sums(Xd, w.order.p, w.seg.p, k, d, sums_dev, counts_dev, kSegSums, w.seg_ws, cx.st));
   VI_HIP(hipStreamSynchronize(cx.st));
   return VI_OK;
 }

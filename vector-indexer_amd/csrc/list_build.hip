@@ -5,9 +5,9 @@
 // Here the points never leave HBM between k-means and search:
 //
 //   labels (device, from the final assignment)
-//     -> keys (label << 32 | id), sorted by the device-wide bitonic sort of generic_search.hip: ids grouped by list,
-//        ascending inside a list — no atomics, so the order is the reference's, run after run
-//     -> list offsets by binary search of the sorted keys
+//     -> ids grouped by list, ascending inside a list: a stable radix sort on the label (8 bits per pass, two passes up
+//        to 65 536 lists) — no atomics decide a position, so the order is the reference's, run after run
+//     -> list offsets by binary search of the sorted labels
 //     -> the lane-interleaved blocks + bf16 images of the resident index straight from X (device_index_from_order):
 //        nothing is re-read from the shard files the build has just written
 //     -> shard files: one kernel per shard lays the records (24 B meta + D f32 + pad) out in file order in a staging
@@ -25,8 +25,6 @@
 
 namespace vi {
 
-// generic_search.hip: rows of 2^logL u64 keys, ascending (logL >= 11)
-vi_status sort_rows_u64(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream_t st);
 // search_kernels.hip
 vi_status init_device_index_pub(DeviceIndex *ix, int device, uint32_t dim, uint64_t nlists);
 
@@ -34,28 +32,126 @@ namespace {
 
 constexpr int kWave = 64;
 
-__global__ void make_keys_kernel(const uint32_t *labels, uint64_t n, uint64_t total, uint64_t *keys) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  keys[i] = i < n ? (((uint64_t)labels[i] << 32) | i) : ~0ull;
+// ---- stable grouping of ids by label: least-significant-digit radix sort, 8 bits per pass -------------------------
+// A pass reads (label, id) pairs in their current order and writes them grouped by one digit of the label, keeping the
+// order inside a digit — after the last pass the ids are grouped by label, ascending inside a label (the first pass reads
+// the ids as positions, i.e. ascending).  No atomics decide a position: the result is the reference's ascending-id lists
+// (src/ivf_index.rs:94-101) and the ascending member order of update_centroids_parallel (src/kmeans.rs:693-697), run
+// after run.  Work per pass: 8 B read + 8 B written per element and a 256 x tiles histogram — HBM bound.
+constexpr int kRadixThreads = 256, kRadixItems = 16, kRadixTile = kRadixThreads * kRadixItems;  // 4096 elements per tile
+
+// element e of a tile belongs to wave e / 1024, item (e % 1024) / 64, lane e % 64: an item is one coalesced load
+__device__ __forceinline__ uint64_t radix_elem(uint64_t tile, int wave, int item, int lane) {
+  return tile * kRadixTile + (uint64_t)wave * (kRadixItems * kWave) + (uint64_t)item * kWave + lane;
 }
 
-// off[c] = first sorted position whose label is >= c (c = 0..k), order[i] = id of sorted position i
-__global__ void offsets_kernel(const uint64_t *keys, uint64_t n, uint32_t k, uint64_t *off) {
+// counts[digit * ntiles + tile] = elements of the tile with that digit
+__global__ void __launch_bounds__(kRadixThreads) radix_hist_kernel(const uint32_t *keys, uint64_t n, uint32_t shift,
+                                                                   uint32_t ntiles, uint32_t *counts) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int it = 0; it < kRadixItems; ++it) {
+    const uint64_t e = radix_elem(blockIdx.x, wave, it, lane);
+    if (e < n) atomicAdd(&hist[(keys[e] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  counts[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// per digit: exclusive scan of its row of tile counts in place, digit_total[digit] = the row's sum
+__global__ void __launch_bounds__(256) radix_scan_rows_kernel(uint32_t *counts, uint32_t ntiles, uint32_t *digit_total) {
+  __shared__ uint32_t wsum[4];
+  uint32_t *row = counts + (size_t)blockIdx.x * ntiles;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += 256) {
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t v = t < ntiles ? row[t] : 0u;
+    uint32_t inc = v;  // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) before += wsum[w]; all += wsum[w]; }
+    if (t < ntiles) row[t] = carry + before + inc - v;
+    carry += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = carry;
+}
+
+// digit_base[d] = elements with a smaller digit (256 threads, one workgroup)
+__global__ void __launch_bounds__(256) radix_scan_digits_kernel(const uint32_t *digit_total, uint32_t *digit_base) {
+  __shared__ uint32_t tot[256];
+  tot[threadIdx.x] = digit_total[threadIdx.x];
+  __syncthreads();
+  uint32_t b = 0;
+  for (uint32_t d = 0; d < threadIdx.x; ++d) b += tot[d];
+  digit_base[threadIdx.x] = b;
+}
+
+// ids_in == nullptr: the id of element e is e
+__global__ void __launch_bounds__(kRadixThreads) radix_scatter_kernel(const uint32_t *keys_in, const uint32_t *ids_in, uint64_t n,
+                                                                      uint32_t shift, uint32_t ntiles, const uint32_t *counts,
+                                                                      const uint32_t *digit_base, uint32_t *keys_out,
+                                                                      uint32_t *ids_out) {
+  __shared__ uint32_t cnt[4][256];   // per wave: elements of each digit seen so far (then: its first output position)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t key[kRadixItems], rank[kRadixItems];
+  const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int it = 0; it < kRadixItems; ++it) {
+    const uint64_t e = radix_elem(blockIdx.x, wave, it, lane);
+    const bool valid = e < n;
+    key[it] = valid ? keys_in[e] : 0u;
+    const uint32_t digit = (key[it] >> shift) & 255u;
+    uint64_t peers = __ballot(valid);  // lanes of this item with the same digit
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t before = (uint32_t)__popcll(peers & lt);
+    const uint32_t prior = cnt[wave][digit];                 // (a wave's LDS accesses execute in program order)
+    if (valid && before == 0) cnt[wave][digit] = prior + (uint32_t)__popcll(peers);
+    rank[it] = prior + before;
+  }
+  __syncthreads();
+  {  // thread = digit: where each wave's elements of this digit start in the output
+    const uint32_t dgt = threadIdx.x;
+    uint32_t pos = digit_base[dgt] + counts[(size_t)dgt * ntiles + blockIdx.x];
+    for (int w = 0; w < 4; ++w) { const uint32_t c = cnt[w][dgt]; cnt[w][dgt] = pos; pos += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kRadixItems; ++it) {
+    const uint64_t e = radix_elem(blockIdx.x, wave, it, lane);
+    if (e < n) {
+      const uint32_t pos = cnt[wave][(key[it] >> shift) & 255u] + rank[it];
+      keys_out[pos] = key[it];
+      ids_out[pos] = ids_in ? ids_in[e] : (uint32_t)e;
+    }
+  }
+}
+
+// off[c] = first sorted position whose label is >= c (c = 0..k)
+__global__ void offsets_kernel(const uint32_t *sorted_labels, uint64_t n, uint32_t k, uint32_t *off) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > k) return;
-  const uint64_t want = (uint64_t)c << 32;
-  uint64_t lo = 0, hi = n;  // first i in [0, n] with keys[i] >= want
+  uint64_t lo = 0, hi = n;  // first i in [0, n] with sorted_labels[i] >= c
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
-    if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    if (sorted_labels[mid] < c) lo = mid + 1; else hi = mid;
   }
-  off[c] = lo;
-}
-
-__global__ void take_ids_kernel(const uint64_t *keys, uint64_t n, uint32_t *order) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) order[i] = (uint32_t)keys[i];
+  off[c] = (uint32_t)lo;
 }
 
 // one workgroup per kept list: row_of_slot of its blocks (pad lanes = kNoPos)
@@ -123,25 +219,54 @@ vi_status upload(DevBuf<T> &buf, const T *host, size_t n, hipStream_t st) {
 
 }  // namespace
 
-// ids 0..n-1 grouped by label (ascending id inside a label): order (device) and off[k+1] (host)
+// ids 0..n-1 grouped by label (ascending id inside a label): order (device, n u32), seg (device, k+1 u32: list c is
+// order[seg[c] .. seg[c+1])) and, if asked for, the same offsets on the host.  Labels must be < k.
 vi_status group_ids_by_label_device(const uint32_t *labels_dev, uint64_t n, uint64_t k, DevBuf<uint32_t> &order,
-                                    std::vector<uint64_t> &off, hipStream_t st) {
-  uint32_t logL = 11;
-  while ((1ull << logL) < n) ++logL;
-  const uint64_t total = 1ull << logL;
-  DevBuf<uint64_t> keys, doff;
-  VI_TRY(keys.reserve(total));
-  VI_TRY(doff.reserve(k + 1));
+                                    DevBuf<uint32_t> &seg, std::vector<uint64_t> *off_host, hipStream_t st,
+                                    DevBuf<uint32_t> *scratch_keep) {
+  if (n > 0xFFFFFFFEull || k > 0xFFFFFFFEull) return fail(VI_ERR_INVALID_INPUT, "more than 2^32 - 2 points or lists");
   VI_TRY(order.reserve(std::max<uint64_t>(n, 1)));
-  hipLaunchKernelGGL(make_keys_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, labels_dev, n, total, keys.p);
+  VI_TRY(seg.reserve(k + 1));
+  if (n == 0) {  // a rank that owns no points: every list empty
+    VI_HIP(hipMemsetAsync(seg.p, 0, (k + 1) * 4, st));
+    if (off_host) off_host->assign(k + 1, 0);
+    VI_HIP(hipStreamSynchronize(st));
+    return VI_OK;
+  }
+  uint32_t bits = 1;
+  while (bits < 32 && ((k - 1) >> bits) != 0) ++bits;
+  const uint32_t passes = (bits + 7) / 8;
+  const uint32_t ntiles = (uint32_t)((n + kRadixTile - 1) / kRadixTile);
+  DevBuf<uint32_t> keys[2], ids_tmp, counts, digit_total, digit_base;
+  VI_TRY(keys[0].reserve(n));
+  if (passes > 1) { VI_TRY(keys[1].reserve(n)); VI_TRY(ids_tmp.reserve(n)); }
+  VI_TRY(counts.reserve((size_t)256 * ntiles));
+  VI_TRY(digit_total.reserve(256));
+  VI_TRY(digit_base.reserve(256));
+  // the ids ping-pong between ids_tmp and order such that the LAST pass writes into order
+  const uint32_t *kin = labels_dev, *iin = nullptr;
+  for (uint32_t p = 0; p < passes; ++p) {
+    uint32_t *kout = keys[p & 1].p;
+    uint32_t *iout = ((passes - 1 - p) & 1) ? ids_tmp.p : order.p;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kRadixThreads), 0, st, kin, n, 8 * p, ntiles, counts.p);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(256), 0, st, counts.p, ntiles, digit_total.p);
+    hipLaunchKernelGGL(radix_scan_digits_kernel, dim3(1), dim3(256), 0, st, digit_total.p, digit_base.p);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kRadixThreads), 0, st, kin, iin, n, 8 * p, ntiles, counts.p,
+                       digit_base.p, kout, iout);
+    VI_HIP(hipGetLastError());
+    kin = kout;
+    iin = iout;
+  }
+  hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)((k + 1 + 255) / 256)), dim3(256), 0, st, kin, n, (uint32_t)k, seg.p);
   VI_HIP(hipGetLastError());
-  VI_TRY(sort_rows_u64(keys.p, 1, logL, st));
-  hipLaunchKernelGGL(offsets_kernel, dim3((uint32_t)((k + 1 + 255) / 256)), dim3(256), 0, st, keys.p, n, (uint32_t)k, doff.p);
-  hipLaunchKernelGGL(take_ids_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, keys.p, n, order.p);
-  VI_HIP(hipGetLastError());
-  off.resize(k + 1);
-  VI_HIP(hipMemcpyAsync(off.data(), doff.p, (k + 1) * 8, hipMemcpyDeviceToHost, st));
-  VI_HIP(hipStreamSynchronize(st));
+  if (off_host) {
+    std::vector<uint32_t> o32(k + 1);
+    VI_HIP(hipMemcpyAsync(o32.data(), seg.p, (k + 1) * 4, hipMemcpyDeviceToHost, st));
+    VI_HIP(hipStreamSynchronize(st));
+    off_host->assign(o32.begin(), o32.end());
+  } else {
+    VI_HIP(hipStreamSynchronize(st));  // the scratch buffers above are freed on return
+  }
   return VI_OK;
 }
 
