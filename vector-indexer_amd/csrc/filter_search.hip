@@ -49,6 +49,7 @@
 #include "rank_stream.hpp"
 #include "scan.hpp"
 #include "wave_select.hpp"
+#include "wave_sort.hpp"
 
 namespace vi {
 
@@ -1086,7 +1087,7 @@ constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/
 
 // One wave: top-K of query q under (exact distance, (g << 26) | position) from its G group records at gbase.
 // Leaves the result in `sel` (entry e of lane i = result 64e + i, key kNoPos when there are fewer than K).
-// Top = WaveTopK (K <= 64) or WaveTop128 (K <= 128: the Faiss-style harness asks for 100 neighbours).
+// Top = FastTopK (K <= 64) or FastTop128 (K <= 128: the Faiss-style harness asks for 100 neighbours), wave_sort.hpp.
 template <class Top>
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick, float4 *tcache,
@@ -1428,11 +1429,11 @@ __global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) 
     pr.ng = a.recs; pr.len = a.nlists; pr.segb = a.segb;
     pr.boff = (q / a.c.gq) * (a.recs / 2u) * seg_records(a.segb) * (2u * a.c.gq) + (q % a.c.gq);  // pairs = iota: the query's own position
   }
-  WaveTopK sel;
-  select_body<WaveTopK>(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
+  FastTopK sel;
+  select_body<FastTopK>(a.c, q, (size_t)q * a.recs, a.recs, 1u, pr, a.P, lane, s_pick[wave], s_tcache[wave],
               s_lcache[wave], s_q[wave], sel);
-  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
-  const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
+  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.ent_p(0) != kNoPos));
+  const uint32_t mylist = (uint32_t)lane < found ? sel.ent_p(0) : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
@@ -1513,18 +1514,18 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
       const float4 r = record(i);
       lm = min3_raw(lm, r.x, r.z);
     }
-  WaveTopK s1;
+  FastTopK s1;
   s1.init();
   s1 = offer_bulk_fn(s1, lm, (uint32_t)lane, (int)K);
   float thr = INFINITY;
   {
-    const float mk = readlane_f(s1.d, (int)K - 1);
+    const float mk = s1.kth((int)K);
     if (!distrust && mk < 1.0e37f) {
       const float scale = fmaxf(mk + qn, 0.0f) + E;
       thr = mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
     }
   }
-  WaveTopK sel;
+  FastTopK sel;
   sel.init();
   uint32_t npick = 0, nwhole = 0;
   auto exact_rows = [&](bool live, uint32_t pos) {
@@ -1592,8 +1593,8 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   drain_whole();
   drain_singles();
   // ---- the same tail as coarse_select_kernel: probes, candidate order, histogram, record offsets of the list phase ----
-  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.p != kNoPos));
-  const uint32_t mylist = (uint32_t)lane < found ? sel.p : kNoPos;
+  const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.ent_p(0) != kNoPos));
+  const uint32_t mylist = (uint32_t)lane < found ? sel.ent_p(0) : kNoPos;
   const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
@@ -2158,8 +2159,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     { const char *e = getenv("VI_EXACT_BF16"); if (ix.lists_hi_nat.p && !(e && *e == '0')) a.c.hi_nat = (const uint4 *)ix.lists_hi_nat.p; }
     { const char *e = getenv("VI_EXACT_U8"); if (ix.lists_u8_nat.p && !(e && *e == '0')) a.c.u8_nat = (const uint4 *)ix.lists_u8_nat.p; }
     const size_t qsm = 4ull * ix.dim * sizeof(float);
-    if (k <= 64) hipLaunchKernelGGL(select_kernel<WaveTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
-    else hipLaunchKernelGGL(select_kernel<WaveTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
+    if (k <= 64) hipLaunchKernelGGL(select_kernel<FastTopK>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
+    else hipLaunchKernelGGL(select_kernel<FastTop128>, dim3((uint32_t)((nq + 3) / 4)), dim3(256), qsm, st, a);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[4], st));
