@@ -36,7 +36,9 @@
 #include <vector>
 
 #include "assign_mfma.hpp"
+#include "device_math.hpp"
 #include "mfma_bf16.hpp"
+#include "wave_sort.hpp"
 
 namespace vi {
 namespace {
@@ -346,6 +348,232 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_bf16_kernel(MfmaArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// hi-only candidate sweep: ONE bf16 MFMA per product instead of three
+// ------------------------------------------------------------------------------------------
+// m0(i,c) = ||c||^2 - 2 hi(x_i).hi(c) differs from ||c||^2 - 2 x_i.c by at most E0_i = 2^-7 (1 + 2^-9) (||x_i||^2 +
+// max||c||^2) + the accumulation error — bf16 keeps 8 significant bits (|x - hi(x)| <= 2^-8 |x|), so
+// 2 |x.c - hi(x).hi(c)| <= 2^-6 (1 + 2^-9) |x||c|.  That is far too coarse to NAME the nearest centroid (the best and
+// second best of a point are ~2 % apart: 3.6 of 160 at C3, the margin is 5), but it is enough to name the few that can
+// be it: with c* the reference's arg-min,
+//     m0(i,c*) <= m0(i,c') + 2 (E0_i + G_i)      for EVERY c'                               (**)
+// (G_i: the reference's own rounding, file header), in particular for the centroid that holds the running minimum
+// when c* comes by.  So a sweep that lists, per point, every centroid whose m0 is within the margin of the running
+// minimum lists c* (and every centroid tied with it), and the exact lane-order distance (src/kmeans.rs:377-419) of
+// the listed few decides — ~6 candidates per point at C3 once the running minimum has seen 1 024 centroids (the first
+// `warm` tiles are swept without listing and once more at the end), 2.5 of which are within the margin of the final
+// minimum.  Points that list more than kCandCap per lane half (or nothing: NaN rows) go to the tiers above.
+//
+// Tiling: workgroup = 4 waves x 64 points; a wave keeps its 2 x 32 points' hi planes in registers (B operand, 64 VGPRs at
+// D = 128) and multiplies each LDS fragment of the centroid tile with both — 32 MFMAs and 16 ds_read_b128 per 64
+// centroids.  The epilogue of a 32 x 32 accumulator tile is its minimum (12 instructions) and one compare against the
+// lane's threshold; only when some lane has a candidate (27 % of the tiles) are the 16 values looked at one by one.
+constexpr int kCandCap = 16;     // candidates a (point, lane half) may list
+constexpr uint32_t kCandWarmTiles = 16;
+
+struct CandArgs {
+  const float *X;
+  uint32_t n, dim;
+  const float4 *img;  // hi image of the centroid tiles: [tile][chunk][half of 8 dims][64] x 16 B
+  const float *cn;    // norms padded to whole tiles (+inf)
+  uint32_t k, ntiles, warm;
+  float margin_scale_x, margin_const;
+  uint32_t *cand, *cand_cnt;  // [(point * 2 + lane half) * kCandCap + slot], [point * 2 + lane half]
+};
+
+__global__ void centroid_hi_image_kernel(const float *C, uint32_t k, uint32_t d, uint32_t nc, uint4 *img) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, chunk, half, vector)
+  const uint64_t ntiles = (k + 63) / 64;
+  if (t >= ntiles * nc * 128) return;
+  const uint32_t v = (uint32_t)(t & 63), h = (uint32_t)((t >> 6) & 1);
+  const uint64_t bc = t >> 7;
+  const uint32_t c = (uint32_t)(bc % nc);
+  const uint64_t b = bc / nc;
+  const uint64_t row = b * 64 + v;
+  const uint32_t e = 16 * c + 8 * h;
+  float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+  if (row < k && e < d) x0 = *reinterpret_cast<const float4 *>(C + row * d + e);
+  if (row < k && e + 4 < d) x1 = *reinterpret_cast<const float4 *>(C + row * d + e + 4);
+  uint4 hi, lo;
+  split8(x0, x1, 1.0f, hi, lo);
+  img[((b * nc + c) * 2 + h) * 64 + v] = hi;
+}
+
+template <int NC>  // dims padded to 16 * NC (NC <= 8)
+__global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
+  extern __shared__ float lds[];
+  constexpr int kImgFloats = 2 * NC * 256 + 64;  // image + 64 norms
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  // B fragments: two points per lane (tile p: point 32p + j of the wave), dims 16c + 8h .., scaled by -2 (exact), hi plane
+  float4 xb[2][NC];
+  float margin[2];
+  uint32_t slot0[2];
+  bool live[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const uint32_t pt = blockIdx.x * 256 + wave * 64 + 32 * p + j;
+    live[p] = pt < a.n;
+    const float *row = a.X + (size_t)(live[p] ? pt : 0) * a.dim;
+    float xnv = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const uint32_t e = 16 * c + 8 * h;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (live[p] && e < a.dim) v0 = *reinterpret_cast<const float4 *>(row + e);
+      if (live[p] && e + 4 < a.dim) v1 = *reinterpret_cast<const float4 *>(row + e + 4);
+      xnv += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+      uint4 hi, lo;
+      split8(v0, v1, -2.0f, hi, lo);
+      xb[p][c] = __builtin_bit_cast(float4, hi);
+    }
+    const float xnt = xnv + __shfl_xor(xnv, 32);
+    margin[p] = a.margin_scale_x * xnt + a.margin_const;
+    slot0[p] = (pt * 2u + (uint32_t)h) * (uint32_t)kCandCap;
+  }
+  float b1[2] = {INFINITY, INFINITY}, thr[2] = {INFINITY, INFINITY};
+  uint32_t cnt[2] = {0u, 0u};
+  uint32_t *lists = reinterpret_cast<uint32_t *>(lds + 2 * kImgFloats);  // [point tile][slot][thread]: 2 x kCandCap x 256 words
+
+  const size_t img_stride = (size_t)2 * NC * 64;  // float4 per tile image
+  const uint32_t steps = a.ntiles + a.warm;       // tiles 0 .. ntiles-1 (the first `warm` without listing), then 0 .. warm-1 again
+  tile_dma_image<NC>(lds, a.img, a.cn, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (uint32_t s = 0; s < steps; ++s) {
+    const float *cur = lds + (s & 1) * kImgFloats;
+    const uint32_t ct = s < a.ntiles ? s : s - a.ntiles;
+    const bool record = s >= a.warm;
+    if (s + 1 < steps) {  // next tile into the other buffer during this tile's MFMAs (asm copies: see mfma_assign_bf16_kernel)
+      const uint32_t nt = s + 1 < a.ntiles ? s + 1 : s + 1 - a.ntiles;
+      tile_dma_image_asm<NC>(lds + ((s + 1) & 1) * kImgFloats, a.img + nt * img_stride, a.cn + (size_t)nt * kTileC, wave, lane);
+    }
+    f32x16 acc[2][2];  // [centroid row tile][point tile]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // rows 8q + 4h + (0..3) live in regs 4q .. 4q+3
+      const float4 n0 = *reinterpret_cast<const float4 *>(cur + 2 * NC * 256 + 8 * q + 4 * h);
+      const float4 n1 = *reinterpret_cast<const float4 *>(cur + 2 * NC * 256 + 32 + 8 * q + 4 * h);
+      acc[0][0][4 * q + 0] = n0.x; acc[0][0][4 * q + 1] = n0.y; acc[0][0][4 * q + 2] = n0.z; acc[0][0][4 * q + 3] = n0.w;
+      acc[1][0][4 * q + 0] = n1.x; acc[1][0][4 * q + 1] = n1.y; acc[1][0][4 * q + 2] = n1.z; acc[1][0][4 * q + 3] = n1.w;
+    }
+    acc[0][1] = acc[0][0];
+    acc[1][1] = acc[1][0];
+    auto frag = [&](int c, int t) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(cur + ((c * 2 + h) * 64 + 32 * t + j) * 4));
+    };
+    bf16x8 a0 = frag(0, 0), a1 = frag(0, 1);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bf16x8 p0 = __builtin_bit_cast(bf16x8, xb[0][c]), p1 = __builtin_bit_cast(bf16x8, xb[1][c]);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, p0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, p0, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, p1, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, p1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NC) { a0 = frag(c + 1, 0); a1 = frag(c + 1, 1); }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float smin = INFINITY;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float tmin = tile_min(acc[rt][p]);
+        const bool flag = record && live[p] && !(tmin > thr[p]);  // (!(x > thr): a NaN is listed, never skipped)
+        if (__ballot(flag)) {  // some lane has a candidate among its 16 values (a third of the tiles): which ones?
+          uint32_t hits = 0u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hits |= !(acc[rt][p][r] > thr[p]) ? (1u << r) : 0u;
+          hits = flag ? hits : 0u;
+          while (hits) {  // (one hit as a rule: the tile's minimum)
+            const uint32_t r = (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1u;
+            if (cnt[p] < (uint32_t)kCandCap) lists[(p * kCandCap + cnt[p]) * 256 + threadIdx.x] = ct * kTileC + rt * 32 + (r & 3u) + 8u * (r >> 2) + 4u * h;
+            ++cnt[p];
+          }
+        }
+        smin = fminf(smin, tmin);
+      }
+      // the running minimum of the POINT: both lane halves (disjoint centroid rows) share it — (**) holds for every c'
+      smin = fminf(smin, __uint_as_float(exchange_u32<Ex::X32>(__float_as_uint(smin), lane)));
+      b1[p] = fminf(b1[p], smin);
+      thr[p] = b1[p] + margin[p];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // next tile visible; this one free to be overwritten
+  }
+  // the lists leave LDS once (a global store inside the sweep would make the step's vmcnt(0) wait for its round trip)
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    if (live[p]) {
+      const uint32_t m = min(cnt[p], (uint32_t)kCandCap);
+      for (uint32_t i = 0; i < m; ++i) a.cand[slot0[p] + i] = lists[(p * kCandCap + i) * 256 + threadIdx.x];
+      a.cand_cnt[slot0[p] / (uint32_t)kCandCap] = cnt[p];
+    }
+}
+
+// the listed candidates of a point in the reference's own arithmetic: arg-min of compute_distance_simd under
+// (distance, centroid index) — find_nearest_centroid's strict '<' over ascending indices (src/kmeans.rs:355-373).
+// Points whose lists overflowed, are empty, or hold no finite distance go to the ambiguous list (exact over all centroids).
+__global__ void __launch_bounds__(256) cand_exact_kernel(const float *X, uint32_t n, uint32_t d, const float *C, uint32_t k,
+                                                         const uint32_t *cand, const uint32_t *cand_cnt, uint32_t *label,
+                                                         uint32_t *amb_list, uint32_t *namb) {
+  // 8 lanes per point: lane l owns the reference's l-th lane accumulator (dims l, 8 + l, ...: kmeans.rs:387-396), lanes
+  // 0..3 its 4-lane accumulators (:399-408), lane 0 the scalar tail (:411-416) and the final reduction (:418)
+  const uint32_t pt = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7u;
+  const int lane = threadIdx.x & 63, g0 = lane & ~7;
+  const bool in = pt < n;
+  const uint32_t n0 = in ? cand_cnt[2 * pt] : 0u, n1 = in ? cand_cnt[2 * pt + 1] : 0u;
+  const bool ok = in && n0 <= (uint32_t)kCandCap && n1 <= (uint32_t)kCandCap;
+  const uint32_t total = ok ? n0 + n1 : 0u;
+  const float *x = X + (size_t)(in ? pt : 0u) * d;
+  const uint32_t d8 = d & ~7u, has4 = (d & 4u) ? 1u : 0u;
+  float best = INFINITY;
+  uint32_t bc = 0xFFFFFFFFu;
+  uint32_t tmax = total;  // (the wave's eight points go round together)
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o));
+  for (uint32_t i = 0; i < tmax; ++i) {
+    const bool have = i < total;
+    uint32_t c = have ? cand[(size_t)(2 * pt + (i < n0 ? 0u : 1u)) * kCandCap + (i < n0 ? i : i - n0)] : 0u;
+    const bool valid = have && c < k;  // (pad rows of the last tile carry +inf norms and are never listed; belt and braces)
+    c = valid ? c : 0u;
+    const float *cr = C + (size_t)c * d;
+    float a8 = 0.0f, a4 = 0.0f, tail = 0.0f;
+    for (uint32_t j = 0; j < d8; j += 8) sq_add(a8, x[j + l], cr[j + l]);
+    if (has4 && l < 4u) sq_add(a4, x[d8 + l], cr[d8 + l]);
+    if (l == 0u)
+      for (uint32_t j = d8 + 4u * has4; j < d; ++j) sq_add(tail, x[j], cr[j]);
+    float v8[8], v4[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v8[t] = __shfl(a8, g0 + t);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v4[t] = __shfl(a4, g0 + t);
+    const float lo = VI_REDUCE4(v8[0], v8[1], v8[2], v8[3]);  // include/vi_reduce_order.h, as l2sq_lanes_dev
+    const float hi = VI_REDUCE4(v8[4], v8[5], v8[6], v8[7]);
+    const float r4 = VI_REDUCE4(v4[0], v4[1], v4[2], v4[3]);
+    const float dist = ((lo + hi) + r4) + __shfl(tail, g0);
+    if (valid && (dist < best || (dist == best && c < bc))) { best = dist; bc = c; }
+  }
+  if (in && l == 0u) {
+    if (bc == 0xFFFFFFFFu) {
+      label[pt] = 0u;
+      amb_list[atomicAdd(namb, 1u)] = pt;
+    } else {
+      label[pt] = bc;
+    }
+  }
+}
+
+template <int NC>
+vi_status launch_cand(const CandArgs &a, hipStream_t st) {
+  const size_t smem = 2 * (2 * NC * 256 + 64) * sizeof(float) + 2 * kCandCap * 256 * sizeof(uint32_t);
+  VI_HIP(hipFuncSetAttribute((const void *)mfma_assign_cand_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((mfma_assign_cand_kernel<NC>), dim3((a.n + 255) / 256), dim3(256), smem, st, a);
+  VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
 template <int NG>
 vi_status launch_mfma_bf16(const MfmaArgs &a, hipStream_t st) {
   const size_t smem = 2 * (2 * NG * 256 + 64) * sizeof(float);
@@ -412,11 +640,12 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   double cmax = 0.0;
   for (uint64_t c = 0; c < k; ++c) cmax = std::max(cmax, (double)h_cn[c]);
   // margin_i = 2 (E_i + G_i), see the file header; computed in double, rounded up.  bf16 x 3: E grows to
-  // (3D+2) 2u' (accumulating 3D exact bf16 products; 2u' also covers a truncating accumulator) + 3 * 2^-18
-  // (the dropped lo.lo product and the two split residuals)
+  // (3D+2) 2u' (accumulating 3D exact bf16 products; 2u' also covers a truncating accumulator) + 2^-15
+  // (the dropped lo.lo product and the two split residuals: |x - hi| <= 2^-8 |x|, |x - hi - lo| <= 2^-17 |x|, so
+  // 2 (|xl.cl| + |xr.c| + |x.cr|) <= 2^-14 |x||c| <= 2^-15 (|x|^2 + |c|^2); round 2 budgeted 3 * 2^-18, too little)
   static const bool bf16 = [] { const char *e = getenv("VI_ASSIGN_BF16"); return !(e && *e == '0'); }();
   const double u = 1.01 * std::ldexp(1.0, -24);
-  const double e = bf16 ? (3.0 * d + 2.0) * 2.0 * u + 3.03 * std::ldexp(1.0, -18) : (d + 2.0) * u;
+  const double e = bf16 ? (3.0 * d + 2.0) * 2.0 * u + 1.01 * std::ldexp(1.0, -15) : (d + 2.0) * u;
   const double e32 = (d + 2.0) * u;
   const double g = (d / 8.0 + 8.0) * u * 2.0;
   MfmaArgs a{};
@@ -439,18 +668,59 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     a.img = (const float4 *)ws.img.p;
     a.cn = ws.cnpad.p;
   }
+  // tier 0: the hi-only candidate sweep (one MFMA per product) + exact evaluation of the listed candidates; what it
+  // cannot decide (list overflow, NaN rows) continues through the tiers below.  VI_ASSIGN_CAND=0: start at bf16 x 3.
+  static const bool cand_on = [] { const char *e = getenv("VI_ASSIGN_CAND"); return !(e && *e == '0'); }();
+  const bool use_cand = bf16 && cand_on && k >= 64ull * 8 * kCandWarmTiles;
+  CandArgs ca{};
+  if (use_cand) {
+    const uint64_t ntiles = (k + 63) / 64, nc = ngb / 2;
+    // 2 |x.c - hi(x).hi(c)| <= 2 (|x - hi(x)||c| + |hi(x)||c - hi(c)|) <= 2^-6 (1 + 2^-9) |x||c| <= e_tr (|x|^2 + |c|^2)
+    const double e_tr = std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) * 1.01;
+    const double e_acc = (d + 2.0) * 2.0 * u;  // f32 accumulation of D exact bf16 products + the norm, per (|x|^2 + 2 max|c|^2)
+    VI_TRY(ws.img_hi.reserve(ntiles * nc * 2 * 64 * 4));
+    const uint64_t nt = ntiles * nc * 128;
+    hipLaunchKernelGGL(centroid_hi_image_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Cd, (uint32_t)k, d,
+                       (uint32_t)nc, (uint4 *)ws.img_hi.p);
+    VI_HIP(hipGetLastError());
+    ca.dim = d; ca.img = (const float4 *)ws.img_hi.p; ca.cn = ws.cnpad.p; ca.k = (uint32_t)k; ca.ntiles = (uint32_t)ntiles;
+    ca.warm = kCandWarmTiles;
+    // margin_i = 2 (E0_i + G_i), E0_i = e_tr (|x_i|^2 + max|c|^2) + e_acc (|x_i|^2 + 2 max|c|^2): see the kernel's header
+    ca.margin_scale_x = (float)(2.0 * (e_tr + e_acc + g) * 1.0001);
+    ca.margin_const = (float)(2.0 * (e_tr + 2.0 * e_acc + g) * cmax * 1.0001);
+  }
   uint64_t total_amb = 0, total_tier1 = 0, total_tier2 = 0;
   float ms_filter = 0.0f;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (stats) { VI_HIP(hipEventCreate(&ev0)); VI_HIP(hipEventCreate(&ev1)); }
-  const uint64_t chunk = 1ull << 24;  // points per launch (bounds the ambiguous list)
+  const uint64_t chunk = use_cand ? 1ull << 22 : 1ull << 24;  // points per launch (bounds the ambiguous list and the candidate lists)
   VI_TRY(ws.amb_list.reserve(std::min(chunk, n)));
+  if (use_cand) {
+    VI_TRY(ws.cand.reserve(std::min(chunk, n) * 2 * kCandCap));
+    VI_TRY(ws.cand_cnt.reserve(std::min(chunk, n) * 2));
+  }
   for (uint64_t p0 = 0; p0 < n; p0 += chunk) {
     const uint64_t m = std::min(chunk, n - p0);
     VI_HIP(hipMemsetAsync(ws.namb.p, 0, sizeof(uint32_t), st));
     a.X = Xd + p0 * d; a.n = (uint32_t)m; a.label = labels_dev + p0; a.amb_list = ws.amb_list.p;
     if (stats) VI_HIP(hipEventRecord(ev0, st));
-    if (bf16) {
+    if (use_cand) {
+      ca.X = a.X; ca.n = a.n; ca.cand = ws.cand.p; ca.cand_cnt = ws.cand_cnt.p;
+      switch (ngb / 2) {
+        case 1: VI_TRY(launch_cand<1>(ca, st)); break;
+        case 2: VI_TRY(launch_cand<2>(ca, st)); break;
+        case 3: VI_TRY(launch_cand<3>(ca, st)); break;
+        case 4: VI_TRY(launch_cand<4>(ca, st)); break;
+        case 5: VI_TRY(launch_cand<5>(ca, st)); break;
+        case 6: VI_TRY(launch_cand<6>(ca, st)); break;
+        case 7: VI_TRY(launch_cand<7>(ca, st)); break;
+        default: VI_TRY(launch_cand<8>(ca, st)); break;
+      }
+      if (stats) VI_HIP(hipEventRecord(ev1, st));  // (the sweep alone; the candidates' exact distances count in ms_total)
+      hipLaunchKernelGGL(cand_exact_kernel, dim3((uint32_t)((m * 8 + 255) / 256)), dim3(256), 0, st, a.X, a.n, d, Cd, (uint32_t)k,
+                         ws.cand.p, ws.cand_cnt.p, a.label, ws.amb_list.p, ws.namb.p);
+      VI_HIP(hipGetLastError());
+    } else if (bf16) {
       switch (ngb) {
         case 2: VI_TRY(launch_mfma_bf16<2>(a, st)); break;
         case 4: VI_TRY(launch_mfma_bf16<4>(a, st)); break;
@@ -464,7 +734,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     } else {
       VI_TRY(launch_mfma_f32(a, ng, st));
     }
-    if (stats) VI_HIP(hipEventRecord(ev1, st));
+    if (stats && !use_cand) VI_HIP(hipEventRecord(ev1, st));
     uint32_t namb = 0;
     VI_HIP(hipMemcpyAsync(&namb, ws.namb.p, 4, hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));

@@ -19,6 +19,7 @@ struct MfmaAssignWs {
   DevBuf<float> cn;
   DevBuf<uint32_t> namb, amb_list;
   DevBuf<uint32_t> img;   // bf16 hi/lo images of the centroid tiles
+  DevBuf<uint32_t> img_hi, cand, cand_cnt;  // hi-only candidate sweep: hi image, candidate lists, their lengths
   DevBuf<float> cnpad;    // centroid norms padded to whole tiles (+inf)
   DevBuf<float> xc;       // second tier: gathered ambiguous rows, their labels, what stays ambiguous
   DevBuf<uint32_t> lab_c, amb_list2, namb2;

@@ -1,5 +1,5 @@
 // mfma_bf16.hpp — bf16 x 3 split arithmetic shared by the MFMA ranking kernels (filter_search.hip,
-// assign_mfma.hip).  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|; a product a*b is
+// assign_mfma.hip).  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |x - hi| <= 2^-8 |x|, |r| <= 2^-17 |x|; a product a*b is
 // ranked as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 (bf16 pairs multiply exactly in f32).
 #pragma once
 #include <hip/hip_runtime.h>
