@@ -430,22 +430,53 @@ def main():
         flops = 2.0 * n3 * k3 * d3
         tf = flops / (best[1] * 1e-3) / 1e12
         bf16 = os.environ.get("VI_ASSIGN_BF16", "1") != "0"
+        cand = bf16 and os.environ.get("VI_ASSIGN_CAND", "1") != "0"
+        if cand:
+            kname = ("mfma_assign_cand_kernel<8> (v_mfma_f32_32x32x16_bf16 on the hi planes: ONE MFMA per product; every centroid within the "
+                     "error margin of a point's running minimum is listed and decided by exact lane-order distances)")
+        elif bf16:
+            kname = "mfma_assign_bf16_kernel<16> (v_mfma_f32_32x32x16_bf16, operands split hi+lo: 3 products per multiply)"
+        else:
+            kname = "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)"
         kmeans = {"workload": f"exact nearest-centroid assign N={n3} D={d3} k={k3} (BASELINE config C3), one full pass",
                   "ms_total": round(best[0], 2), "ms_mfma_filter": round(best[1], 2),
-                  "rows_left_by_bf16x3_tier": best[3], "rows_re_evaluated_exactly": best[2],
-                  "roofline": {"kernel": "mfma_assign_bf16_kernel<16> (v_mfma_f32_32x32x16_bf16, operands split hi+lo: 3 products "
-                                         "per multiply)" if bf16 else "mfma_assign_kernel<16,1> (v_mfma_f32_32x32x2_f32)",
+                  "rows_left_by_first_tier": best[3], "rows_re_evaluated_exactly": best[2],
+                  "roofline": {"kernel": kname,
                                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF,
                                "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF), 4),
                                "flops_per_launch": flops,
-                               "frac_of_bf16_peak_over_3": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4) if bf16 else None,
+                               "frac_of_bf16_peak_over_3": round(tf / (MFMA_BF16_PEAK_TF / 3.0), 4) if (bf16 and not cand) else None,
                                "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
-                               "peak_note": "achieved = useful 2*N*k*D flop / time of the first-tier kernel; frac against the "
-                                            "dense bf16 peak; the exact split arithmetic issues 3 MFMAs per product (frac_of_"
-                                            "bf16_peak_over_3 is the share of what that arithmetic can reach)"},
+                               "peak_note": "achieved = useful 2*N*k*D flop / time of the first-tier kernel (HIP events on the library's "
+                                            "stream); frac against the dense bf16 peak.  The sweep issues 1 + 16/256 MFMAs per product "
+                                            "(its first 16 centroid tiles are swept twice); ms_total adds the exact evaluation of the "
+                                            "listed candidates and the rows the lists could not hold"},
                   "hbm_GBps": round((4.0 * n3 * d3 + 4.0 * n3) / (best[1] * 1e-3) / 1e9, 1),
-                  "note": "labels == assign_points_brute_force on every row the tiers leave undecided and 20 000 sampled rows "
-                          "at this k and D (tests/test_baseline_configs_gpu.py::test_c3_exact_assign_k16384, N=1e6)"}
+                  "note": "labels == assign_points_brute_force on every row the first tier leaves undecided and 20 000 sampled rows "
+                          "at this k and D (tests/test_baseline_configs_gpu.py::test_c3_exact_assign_k16384, N=1e6); the whole training "
+                          "run at N=1e7 against the oracle in test_c3_mini_batch_train_n1e7_k16384"}
+        # CPU baseline of this metric: the oracle's assign in the reference's own mode (2-level hierarchy above 100 centroids,
+        # src/kmeans.rs:445-581 — what BASELINE.md promises) and its brute force (what the GPU number computes), on a bounded
+        # sample of the same points against the same centroids
+        if not args.no_cpu_baseline:
+            import oracle_lib as O
+            threads = min(O.lib().orc_max_threads(), O.usable_cpus())
+            Ch = C3.cpu().numpy()
+            cb = {}
+            for mode, m0 in (("hier", 200_000), ("brute", 4_000)):
+                Xs = X3[:m0].cpu().numpy()
+                t0 = time.perf_counter()
+                lo = O.assign(Xs, Ch, seed=42, mode=mode)
+                dt = time.perf_counter() - t0
+                cb[mode] = {"points_per_s": round(m0 / dt, 1), "sample_points": m0, "seconds": round(dt, 2)}
+                if mode == "brute":
+                    cb[mode]["identical_to_gpu_labels"] = bool((lab[:m0].cpu().numpy().astype(np.uint64) == lo).all())
+            kmeans["cpu_baseline"] = {"value": cb["hier"]["points_per_s"], "unit": "points/s", "cores": int(threads), "kind": "port",
+                                      "sample": f"oracle assign_points_hierarchical on the first {cb['hier']['sample_points']} of the {n3} points, "
+                                                f"k={k3} D={d3} (the reference's mode above 100 centroids: approximate); exact brute force on "
+                                                f"{cb['brute']['sample_points']} points: {cb['brute']['points_per_s']} points/s, labels identical to the "
+                                                f"GPU's: {cb['brute']['identical_to_gpu_labels']}",
+                                      "gpu_points_per_s": round(n3 / (best[0] * 1e-3), 1)}
         # update pass (update_centroids_parallel): per-cluster sums + counts of all points, device-resident
         sums = torch.empty((k3, d3), dtype=torch.float32, device=device)
         cnts = torch.empty(k3, dtype=torch.int32, device=device)
@@ -474,8 +505,9 @@ def main():
                                                           Cout.data_ptr(), lab.data_ptr(), C.byref(it)))
             tr_[name] = {"seconds": round(time.perf_counter() - t0, 2), "iterations": int(it.value)}
         kmeans["mini_batch_train"] = {**tr_, "note": "vi_kmeans_mini_batch_device, points resident in HBM; dominated by what the "
-                                      "reference pins to the host: 16 384 sequential k-means++ draws and a full shuffle of 0..N "
-                                      "per iteration (kmeans.rs:722-726)"}
+                                      "reference's semantics keep sequential: 16 384 k-means++ draws (each a left-to-right f32 prefix sum "
+                                      "over 50 000 weights on the host, 54 us) and the draw scan of a full Fisher-Yates shuffle of 0..N "
+                                      "per iteration (kmeans.rs:722-726: 27 ms; keystream from the GPU, only the batch's 256 entries traced)"}
         del X3, C3, lab, Cout
         torch.cuda.empty_cache()
 

@@ -379,6 +379,9 @@ struct CandArgs {
   uint32_t k, ntiles, warm;
   float margin_scale_x, margin_const;
   uint32_t *cand, *cand_cnt;  // [(point * 2 + lane half) * kCandCap + slot], [point * 2 + lane half]
+  float *cand_thr;            // [point]: the final threshold (minimum + margin) — entries listed under an earlier, looser one are dropped
+  uint32_t pack16;            // k <= 65536: an entry is centroid | (its m0 rounded DOWN to bf16) << 16, so that the exact pass can drop them
+  uint32_t xmode;             // ablation knob (VI_CAND_XMODE, wrong results): 1 no candidate listing, 2 no epilogue at all
 };
 
 __global__ void centroid_hi_image_kernel(const float *C, uint32_t k, uint32_t d, uint32_t nc, uint4 *img) {
@@ -402,7 +405,7 @@ __global__ void centroid_hi_image_kernel(const float *C, uint32_t k, uint32_t d,
 template <int NC>  // dims padded to 16 * NC (NC <= 8)
 __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
   extern __shared__ float lds[];
-  constexpr int kImgFloats = 2 * NC * 256 + 64;  // image + 64 norms
+  constexpr int kImgFloats = 2 * NC * 256 + 64;  // the tile's hi image + 64 norms
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   // B fragments: two points per lane (tile p: point 32p + j of the wave), dims 16c + 8h .., scaled by -2 (exact), hi plane
@@ -437,18 +440,25 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
 
   const size_t img_stride = (size_t)2 * NC * 64;  // float4 per tile image
   const uint32_t steps = a.ntiles + a.warm;       // tiles 0 .. ntiles-1 (the first `warm` without listing), then 0 .. warm-1 again
-  tile_dma_image<NC>(lds, a.img, a.cn, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (uint32_t s = 0; s < steps; ++s) {
+  auto tile_of = [&](uint32_t s) { return s < a.ntiles ? s : s - a.ntiles; };
+  auto dma_tile = [&](float *buf, uint32_t tile) {  // asm copies: see mfma_assign_bf16_kernel
+    tile_dma_image_asm<NC>(buf, a.img + tile * img_stride, a.cn + (size_t)tile * kTileC, wave, lane);
+  };
+  // one step: tile tile_of(s) sits in buffer s & 1; the next tile's image is requested first
+  auto step = [&](uint32_t s) {
     const float *cur = lds + (s & 1) * kImgFloats;
-    const uint32_t ct = s < a.ntiles ? s : s - a.ntiles;
+    const uint32_t ct = tile_of(s);
     const bool record = s >= a.warm;
-    if (s + 1 < steps) {  // next tile into the other buffer during this tile's MFMAs (asm copies: see mfma_assign_bf16_kernel)
-      const uint32_t nt = s + 1 < a.ntiles ? s + 1 : s + 1 - a.ntiles;
-      tile_dma_image_asm<NC>(lds + ((s + 1) & 1) * kImgFloats, a.img + nt * img_stride, a.cn + (size_t)nt * kTileC, wave, lane);
-    }
+    if (s + 1 < steps) dma_tile(lds + ((s + 1) & 1) * kImgFloats, tile_of(s + 1));
     f32x16 acc[2][2];  // [centroid row tile][point tile]
+    auto frag = [&](int c, int t) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(cur + ((c * 2 + h) * 64 + 32 * t + j) * 4));
+    };
+    // fragments are requested TWO chunks ahead (three register sets): one chunk's four MFMAs (128 cycles) do not cover
+    // an LDS read when eight waves share the port — requested one chunk ahead, every chunk waited (half the MFMA rate)
+    bf16x8 fa[3][2];
+    fa[0][0] = frag(0, 0); fa[0][1] = frag(0, 1);
+    if (NC > 1) { fa[1][0] = frag(1, 0); fa[1][1] = frag(1, 1); }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // rows 8q + 4h + (0..3) live in regs 4q .. 4q+3
       const float4 n0 = *reinterpret_cast<const float4 *>(cur + 2 * NC * 256 + 8 * q + 4 * h);
@@ -458,38 +468,49 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
     }
     acc[0][1] = acc[0][0];
     acc[1][1] = acc[1][0];
-    auto frag = [&](int c, int t) {
-      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(cur + ((c * 2 + h) * 64 + 32 * t + j) * 4));
-    };
-    bf16x8 a0 = frag(0, 0), a1 = frag(0, 1);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const bf16x8 p0 = __builtin_bit_cast(bf16x8, xb[0][c]), p1 = __builtin_bit_cast(bf16x8, xb[1][c]);
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, p0, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, p0, acc[1][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, p1, acc[0][1], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, p1, acc[1][1], 0, 0, 0);
+      if (c + 2 < NC) { fa[(c + 2) % 3][0] = frag(c + 2, 0); fa[(c + 2) % 3][1] = frag(c + 2, 1); }
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < NC) { a0 = frag(c + 1, 0); a1 = frag(c + 1, 1); }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c % 3][0], p0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c % 3][1], p0, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c % 3][0], p1, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c % 3][1], p1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (a.xmode & 2u) {
+      if (acc[0][0][0] + acc[1][0][1] + acc[0][1][2] + acc[1][1][3] == 1.2345f) b1[0] = 0.0f;
+    } else
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       float smin = INFINITY;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const float tmin = tile_min(acc[rt][p]);
-        const bool flag = record && live[p] && !(tmin > thr[p]);  // (!(x > thr): a NaN is listed, never skipped)
+        const bool flag = record && live[p] && !(tmin > thr[p]) && !(a.xmode & 1u);  // (!(x > thr): a NaN is listed, never skipped)
         if (__ballot(flag)) {  // some lane has a candidate among its 16 values (a third of the tiles): which ones?
+          auto append = [&](uint32_t r, float v) {
+            uint32_t entry = ct * kTileC + rt * 32 + (r & 3u) + 8u * (r >> 2) + 4u * h;
+            if (a.pack16) {  // + m0 rounded toward -inf to 16 bits (never above the value: the later filter only keeps too much)
+              const uint32_t vb = __float_as_uint(v);
+              entry |= ((vb & 0x80000000u) ? vb + 0xFFFFu : vb) & 0xFFFF0000u;
+            }
+            if (cnt[p] < (uint32_t)kCandCap) lists[(p * kCandCap + cnt[p]) * 256 + threadIdx.x] = entry;
+            ++cnt[p];
+          };
           uint32_t hits = 0u;
 #pragma unroll
           for (int r = 0; r < 16; ++r) hits |= !(acc[rt][p][r] > thr[p]) ? (1u << r) : 0u;
           hits = flag ? hits : 0u;
-          while (hits) {  // (one hit as a rule: the tile's minimum)
-            const uint32_t r = (uint32_t)__builtin_ctz(hits);
-            hits &= hits - 1u;
-            if (cnt[p] < (uint32_t)kCandCap) lists[(p * kCandCap + cnt[p]) * 256 + threadIdx.x] = ct * kTileC + rt * 32 + (r & 3u) + 8u * (r >> 2) + 4u * h;
-            ++cnt[p];
+          const bool one = hits != 0u && (hits & (hits - 1u)) == 0u;
+          if (one) append((uint32_t)__builtin_ctz(hits), tmin);  // the rule: the tile's minimum alone
+          const bool more = hits != 0u && !one;
+          if (__ballot(more)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (more && ((hits >> r) & 1u)) append((uint32_t)r, acc[rt][p][r]);
           }
         }
         smin = fminf(smin, tmin);
@@ -501,7 +522,11 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next tile visible; this one free to be overwritten
-  }
+  };
+  dma_tile(lds, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (uint32_t s = 0; s < steps; ++s) step(s);
   // the lists leave LDS once (a global store inside the sweep would make the step's vmcnt(0) wait for its round trip)
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -509,6 +534,7 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
       const uint32_t m = min(cnt[p], (uint32_t)kCandCap);
       for (uint32_t i = 0; i < m; ++i) a.cand[slot0[p] + i] = lists[(p * kCandCap + i) * 256 + threadIdx.x];
       a.cand_cnt[slot0[p] / (uint32_t)kCandCap] = cnt[p];
+      if (h == 0) a.cand_thr[slot0[p] / (2u * (uint32_t)kCandCap)] = thr[p];
     }
 }
 
@@ -516,31 +542,57 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
 // (distance, centroid index) — find_nearest_centroid's strict '<' over ascending indices (src/kmeans.rs:355-373).
 // Points whose lists overflowed, are empty, or hold no finite distance go to the ambiguous list (exact over all centroids).
 __global__ void __launch_bounds__(256) cand_exact_kernel(const float *X, uint32_t n, uint32_t d, const float *C, uint32_t k,
-                                                         const uint32_t *cand, const uint32_t *cand_cnt, uint32_t *label,
-                                                         uint32_t *amb_list, uint32_t *namb) {
+                                                         const uint32_t *cand, const uint32_t *cand_cnt, const float *cand_thr,
+                                                         uint32_t pack16, uint32_t *label, uint32_t *amb_list, uint32_t *namb) {
   // 8 lanes per point: lane l owns the reference's l-th lane accumulator (dims l, 8 + l, ...: kmeans.rs:387-396), lanes
-  // 0..3 its 4-lane accumulators (:399-408), lane 0 the scalar tail (:411-416) and the final reduction (:418)
-  const uint32_t pt = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7u;
+  // 0..3 its 4-lane accumulators (:399-408), lane 0 the scalar tail (:411-416) and the final reduction (:418).  The
+  // point's own values stay in registers (d <= 128: 16 per lane); entries listed under a threshold looser than the final
+  // one are dropped first (6 listed, 2.7 kept at C3), the survivors queue up in LDS.
+  __shared__ uint32_t s_keep[32][2 * kCandCap];
+  const uint32_t grp = threadIdx.x >> 3, pt = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, l = threadIdx.x & 7u;
   const int lane = threadIdx.x & 63, g0 = lane & ~7;
   const bool in = pt < n;
   const uint32_t n0 = in ? cand_cnt[2 * pt] : 0u, n1 = in ? cand_cnt[2 * pt + 1] : 0u;
   const bool ok = in && n0 <= (uint32_t)kCandCap && n1 <= (uint32_t)kCandCap;
-  const uint32_t total = ok ? n0 + n1 : 0u;
+  const float thr = in ? cand_thr[pt] : 0.0f;
   const float *x = X + (size_t)(in ? pt : 0u) * d;
   const uint32_t d8 = d & ~7u, has4 = (d & 4u) ? 1u : 0u;
+  float xr[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) xr[t] = (uint32_t)(8 * t) < d8 ? x[8 * t + l] : 0.0f;
+  // survivors of the point's two lists -> s_keep[grp]
+  uint32_t kept = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < 2 * kCandCap; r += 8) {
+    const uint32_t i = r + l;                       // entry i of the concatenated lists
+    const bool have = ok && i < n0 + n1;
+    uint32_t e = have ? cand[(size_t)(2 * pt + (i < n0 ? 0u : 1u)) * kCandCap + (i < n0 ? i : i - n0)] : 0u;
+    bool keep = have;
+    if (pack16) {
+      keep = keep && !(__uint_as_float(e & 0xFFFF0000u) > thr);  // (its rounded-down m0 against the final threshold; NaN stays)
+      e &= 0xFFFFu;
+    }
+    keep = keep && e < k;  // (pad rows of the last tile carry +inf norms and are never listed; belt and braces)
+    const uint32_t bits = (uint32_t)(__ballot(keep) >> g0) & 0xFFu;
+    if (keep) s_keep[grp][kept + (uint32_t)__popc(bits & ((1u << l) - 1u))] = e;
+    kept += (uint32_t)__popc(bits);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float best = INFINITY;
   uint32_t bc = 0xFFFFFFFFu;
-  uint32_t tmax = total;  // (the wave's eight points go round together)
+  uint32_t tmax = kept;  // (the wave's eight points go round together)
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) tmax = max(tmax, (uint32_t)__shfl_xor((int)tmax, o));
   for (uint32_t i = 0; i < tmax; ++i) {
-    const bool have = i < total;
-    uint32_t c = have ? cand[(size_t)(2 * pt + (i < n0 ? 0u : 1u)) * kCandCap + (i < n0 ? i : i - n0)] : 0u;
-    const bool valid = have && c < k;  // (pad rows of the last tile carry +inf norms and are never listed; belt and braces)
-    c = valid ? c : 0u;
+    const bool valid = i < kept;
+    const uint32_t c = valid ? s_keep[grp][i] : 0u;
     const float *cr = C + (size_t)c * d;
     float a8 = 0.0f, a4 = 0.0f, tail = 0.0f;
-    for (uint32_t j = 0; j < d8; j += 8) sq_add(a8, x[j + l], cr[j + l]);
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if ((uint32_t)(8 * t) < d8) sq_add(a8, xr[t], cr[8 * t + l]);
     if (has4 && l < 4u) sq_add(a4, x[d8 + l], cr[d8 + l]);
     if (l == 0u)
       for (uint32_t j = d8 + 4u * has4; j < d; ++j) sq_add(tail, x[j], cr[j]);
@@ -685,6 +737,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     VI_HIP(hipGetLastError());
     ca.dim = d; ca.img = (const float4 *)ws.img_hi.p; ca.cn = ws.cnpad.p; ca.k = (uint32_t)k; ca.ntiles = (uint32_t)ntiles;
     ca.warm = kCandWarmTiles;
+    { const char *xm = getenv("VI_CAND_XMODE"); ca.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
     // margin_i = 2 (E0_i + G_i), E0_i = e_tr (|x_i|^2 + max|c|^2) + e_acc (|x_i|^2 + 2 max|c|^2): see the kernel's header
     ca.margin_scale_x = (float)(2.0 * (e_tr + e_acc + g) * 1.0001);
     ca.margin_const = (float)(2.0 * (e_tr + 2.0 * e_acc + g) * cmax * 1.0001);
@@ -698,6 +751,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   if (use_cand) {
     VI_TRY(ws.cand.reserve(std::min(chunk, n) * 2 * kCandCap));
     VI_TRY(ws.cand_cnt.reserve(std::min(chunk, n) * 2));
+    VI_TRY(ws.cand_thr.reserve(std::min(chunk, n)));
   }
   for (uint64_t p0 = 0; p0 < n; p0 += chunk) {
     const uint64_t m = std::min(chunk, n - p0);
@@ -705,7 +759,8 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
     a.X = Xd + p0 * d; a.n = (uint32_t)m; a.label = labels_dev + p0; a.amb_list = ws.amb_list.p;
     if (stats) VI_HIP(hipEventRecord(ev0, st));
     if (use_cand) {
-      ca.X = a.X; ca.n = a.n; ca.cand = ws.cand.p; ca.cand_cnt = ws.cand_cnt.p;
+      ca.X = a.X; ca.n = a.n; ca.cand = ws.cand.p; ca.cand_cnt = ws.cand_cnt.p; ca.cand_thr = ws.cand_thr.p;
+      ca.pack16 = k <= 65536 ? 1u : 0u;
       switch (ngb / 2) {
         case 1: VI_TRY(launch_cand<1>(ca, st)); break;
         case 2: VI_TRY(launch_cand<2>(ca, st)); break;
@@ -718,7 +773,7 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
       }
       if (stats) VI_HIP(hipEventRecord(ev1, st));  // (the sweep alone; the candidates' exact distances count in ms_total)
       hipLaunchKernelGGL(cand_exact_kernel, dim3((uint32_t)((m * 8 + 255) / 256)), dim3(256), 0, st, a.X, a.n, d, Cd, (uint32_t)k,
-                         ws.cand.p, ws.cand_cnt.p, a.label, ws.amb_list.p, ws.namb.p);
+                         ws.cand.p, ws.cand_cnt.p, ws.cand_thr.p, ca.pack16, a.label, ws.amb_list.p, ws.namb.p);
       VI_HIP(hipGetLastError());
     } else if (bf16) {
       switch (ngb) {

@@ -20,6 +20,7 @@ struct MfmaAssignWs {
   DevBuf<uint32_t> namb, amb_list;
   DevBuf<uint32_t> img;   // bf16 hi/lo images of the centroid tiles
   DevBuf<uint32_t> img_hi, cand, cand_cnt;  // hi-only candidate sweep: hi image, candidate lists, their lengths
+  DevBuf<float> cand_thr;                   // ... and every point's final threshold
   DevBuf<float> cnpad;    // centroid norms padded to whole tiles (+inf)
   DevBuf<float> xc;       // second tier: gathered ambiguous rows, their labels, what stays ambiguous
   DevBuf<uint32_t> lab_c, amb_list2, namb2;
