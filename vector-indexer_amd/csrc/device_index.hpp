@@ -102,6 +102,9 @@ struct DeviceIndex {
   DevBuf<uint32_t> lists_u8_nat;           // 8-bit descriptors (integers 0..255): one byte per dimension, same order (exact re-evaluation)
   DevBuf<uint32_t> lists_hi_nat;           // bf16-exact lists: their hi plane in the blocks' own vector order (exact re-evaluation)
   bool lists_lo_zero = false, cent_lo_zero = false;  // every stored value is bf16-exact (lo planes all zero)
+  // sampled means over the stored vectors: ||v - centroid of its list||^2 and ||v||^2 (what the ranking arithmetic of
+  // real-valued lists is chosen by: filter_search.hip, rank_approx_mode)
+  float mean_spread = 0.0f, mean_norm2 = 0.0f;
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   DevBuf<float> cent_xnorm;           // same for the coarse table
   DevBuf<float> cent_rows;            // the coarse table row-major (coarse select: single-row exact re-evaluation)
