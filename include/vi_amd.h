@@ -268,7 +268,8 @@ vi_status vi_indexer_search_device(const vi_indexer *ix, const float *queries_de
  *   (all-gather of probes / order over the ranks)
  *   vi_indexer_search_probed_device  ivf_index.rs:223-274 for the whole batch against this rank's stripes with the
  *                                    given probe lists; outputs as vi_indexer_search_device.
- * Both return with their outputs complete; all pointers are device pointers; k and n_probe <= 64. */
+ * Both return with their outputs complete; all pointers are device pointers.  Any k and n_probe the single-GPU entry
+ * accepts (k > 128 or n_probe > 64 take the sort-everything path there and here). */
 vi_status vi_indexer_probe_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t n_probe,
                                   uint32_t *probes_dev, uint32_t *order_dev, uint64_t *n_probe_eff);
 vi_status vi_indexer_search_probed_device(const vi_indexer *ix, const float *queries_dev, uint64_t nq, uint64_t k,

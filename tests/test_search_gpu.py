@@ -425,6 +425,53 @@ def test_out_of_range_probe_lists_are_rejected(tmp_path):
         hip.close()
 
 
+def test_striped_ranks_beyond_the_wave_select_limits(tmp_path):
+    """the multi-GPU entries (vi_indexer_probe_device / vi_indexer_search_probed_device) with n_probe > 64 and with
+    k > 128: the split coarse step and the per-rank scans go through the sort-everything path with the caller's probe
+    lists, and the merged result is still the oracle's single search (src/ivf_index.rs:190-267) bit for bit"""
+    from vector_indexer_py import _native
+    rng = np.random.default_rng(31)
+    base = rng.integers(-4, 5, size=(9000, 12)).astype(np.float32)
+    X = np.concatenate([base, base[:800]])
+    orc, full = oracle_and_gpu(tmp_path, X, nlist=150)
+    nl = full.num_centroids
+    assert nl > 80
+    Q = np.concatenate([base[:60], rng.integers(-4, 5, size=(40, 12)).astype(np.float32)])
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    world = 3
+    parts = [vip.load(idx, sh, X.shape[1], rank=r, world_size=world) for r in range(world)]
+    hip = _Hip()
+    try:
+        nq = Q.shape[0]
+        xq = hip.upload(Q)
+        for k, n_probe in [(10, 80), (200, 20), (150, 100), (5, nl + 7)]:
+            p_eff = min(n_probe, nl)
+            probes, order = hip.alloc(nq * p_eff * 4), hip.alloc(nq * p_eff * 4)
+            per = (nq + world - 1) // world
+            for r, p in enumerate(parts):
+                q0, q1 = min(nq, r * per), min(nq, (r + 1) * per)
+                if q1 > q0:
+                    assert p.probe_device(xq + q0 * Q.shape[1] * 4, q1 - q0, n_probe, probes + q0 * p_eff * 4,
+                                          order + q0 * p_eff * 4) == p_eff
+            Dg, Ig, Tg = hip.alloc(world * nq * k * 4), hip.alloc(world * nq * k * 8), hip.alloc(world * nq * k * 8)
+            for r, p in enumerate(parts):
+                p.search_probed_device(xq, nq, k, p_eff, probes, order, Dg + r * nq * k * 4, Ig + r * nq * k * 8, Tg + r * nq * k * 8)
+            rc, Do, Io = orc.search_batch(Q, k, n_probe)
+            assert rc == O.ORC_OK
+            Dm, Im = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+            _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+            assert (hip.download(Im, (nq, k), np.int64) == Io).all(), (k, n_probe)
+            assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), (k, n_probe)
+            # a duplicated order is rejected, not scattered out of bounds
+            bo = hip.download(order, (nq, p_eff), np.uint32).copy()
+            bo[3, 1] = bo[3, 0]
+            with pytest.raises(N.ViError) as e:
+                parts[0].search_probed_device(xq, nq, k, p_eff, probes, hip.upload(bo), Dg, Ig, Tg)
+            assert e.value.kind == "InvalidInput"
+    finally:
+        hip.close()
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_shard_placement_ranks_merge_to_the_single_gpu_result(world, tmp_path):
     """north_star's partition rule (vi_config.placement = 1): whole shard files — the reference's super-centroid grouping,

@@ -148,6 +148,39 @@ __global__ void candidate_offsets_kernel(const uint64_t *order_keys, uint32_t lo
   total[q] = run;
 }
 
+// probe lists given by the caller (another rank's coarse step): the candidate-order ranks of a row's real probes must be
+// distinct — a duplicate would leave a probe without its place in the key rows.  One workgroup per query, a bitmap in LDS.
+__global__ void __launch_bounds__(256) validate_order_kernel(const uint32_t *probes, const uint32_t *order, uint32_t P, uint32_t *bad) {
+  extern __shared__ uint32_t seen[];
+  const uint32_t q = blockIdx.x, words = (P + 31u) / 32u;
+  for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) seen[w] = 0u;
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r < P; r += blockDim.x) {
+    if (probes[(size_t)q * P + r] == kNoPos) continue;
+    const uint32_t g = order[(size_t)q * P + r];
+    if (g >= P || (atomicOr(&seen[g >> 5], 1u << (g & 31u)) >> (g & 31u)) & 1u) atomicOr(bad, 1u);
+  }
+}
+
+// the arrays candidate_offsets_kernel derives from sorted shard keys, from a given order instead: gprobe must be
+// preset to kNoPos (ranks no real probe holds stay empty)
+__global__ void offsets_from_order_kernel(const uint32_t *probes, const uint32_t *gorder, const uint32_t *list_len, uint32_t nq, uint32_t P,
+                                          uint32_t *gprobe, uint32_t *off_by_g, uint32_t *off_by_rank, uint64_t *total) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  for (uint32_t r = 0; r < P; ++r)
+    if (probes[(size_t)q * P + r] != kNoPos) gprobe[(size_t)q * P + gorder[(size_t)q * P + r]] = r;
+  uint64_t run = 0;
+  for (uint32_t g = 0; g < P; ++g) {
+    const uint32_t r = gprobe[(size_t)q * P + g];
+    off_by_g[(size_t)q * P + g] = (uint32_t)run;
+    if (r == kNoPos) continue;
+    off_by_rank[(size_t)q * P + r] = (uint32_t)run;
+    run += list_len[probes[(size_t)q * P + r]];
+  }
+  total[q] = run;
+}
+
 struct OutArgs {
   const uint64_t *keys;
   uint32_t logL, nq, P, k;
@@ -180,7 +213,8 @@ __global__ void generic_output_kernel(OutArgs a) {
     if (off[mid] <= ci) lo = mid; else hi = mid;
   }
   const uint32_t g = lo, pos = ci - off[g];
-  const uint32_t l = a.probes[(size_t)q * a.P + a.gprobe[(size_t)q * a.P + g]];
+  const uint32_t gr = a.gprobe[(size_t)q * a.P + g];
+  const uint32_t l = a.probes[(size_t)q * a.P + (gr < a.P ? gr : 0u)];
   const uint64_t gslot = (uint64_t)a.first_block[l] * 64 + pos;
   a.D[t] = __uint_as_float((uint32_t)(key >> 32));
   a.I[t] = (int64_t)a.ext_ids[gslot];
@@ -197,48 +231,70 @@ vi_status sort_rows_u64(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[14], hipStream_t st, bool histogram_done);
 
-vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
-                                      float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
-                                      hipStream_t st) {
+// declared in search_kernels.hip
+vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
+                       bool histogram, hipStream_t st);
+
+namespace {
+
+// A. probes: dump all coarse distances, sort each row, take the first P -> ws.probes
+vi_status generic_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t dim = ix.dim, dq = ix.dq;
   const uint64_t nlists = ix.nlists;
-  if (ix.nshards > 24576) return fail(VI_ERR_OTHER, "generic path supports at most 24576 shards");
-  vi_search_stats &stt = ix.cur().stats;
-
-  // ---- A. probes: dump all coarse distances, sort each row, take the first P ----
   VI_TRY(ws.probes.reserve(nq * P));
   VI_TRY(ws.gorder.reserve(nq * P));
-  {
-    const uint32_t logLc = log2_ceil_rows(nlists);
-    const uint64_t Lc = 1ull << logLc;
-    const uint64_t qc = std::max<uint64_t>(1, std::min<uint64_t>(nq, kMaxKeys / Lc));
-    VI_TRY(ws.sort_keys.reserve(qc * Lc));
-    const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
-    for (uint64_t q0 = 0; q0 < nq; q0 += qc) {
-      const uint64_t m = std::min(qc, nq - q0);
-      VI_HIP(hipMemsetAsync(ws.sort_keys.p, 0xFF, m * Lc * sizeof(uint64_t), st));
-      const int qg = pick_qg(dq, (double)m, ix.order);
-      uint32_t bps = 0;
-      const uint32_t S = coarse_splits(m, qg, nblk_c, &bps);
-      ScanArgs a{};
-      a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd + q0 * dim; a.nq = (uint32_t)m;
-      a.K = 1; a.nvec = (uint32_t)nlists; a.S = S; a.bps = bps;
-      a.dump_keys = ws.sort_keys.p; a.dump_row = Lc;
-      VI_TRY(launch_scan(a, qg, ix.order, true, (uint32_t)((m + qg - 1) / qg) * S, st));
-      VI_TRY(sort_rows(ws.sort_keys.p, m, logLc, st));
-      hipLaunchKernelGGL(take_probes_kernel, dim3((uint32_t)((m * P + 255) / 256)), dim3(256), 0, st, ws.sort_keys.p,
-                         logLc, (uint32_t)m, P, ws.probes.p + q0 * P);
-      VI_HIP(hipGetLastError());
-    }
+  const uint32_t logLc = log2_ceil_rows(nlists);
+  const uint64_t Lc = 1ull << logLc;
+  const uint64_t qc = std::max<uint64_t>(1, std::min<uint64_t>(nq, kMaxKeys / Lc));
+  VI_TRY(ws.sort_keys.reserve(qc * Lc));
+  const uint32_t nblk_c = (uint32_t)ix.centroids.nblocks;
+  for (uint64_t q0 = 0; q0 < nq; q0 += qc) {
+    const uint64_t m = std::min(qc, nq - q0);
+    VI_HIP(hipMemsetAsync(ws.sort_keys.p, 0xFF, m * Lc * sizeof(uint64_t), st));
+    const int qg = pick_qg(dq, (double)m, ix.order);
+    uint32_t bps = 0;
+    const uint32_t S = coarse_splits(m, qg, nblk_c, &bps);
+    ScanArgs a{};
+    a.blocks = (const float4 *)ix.centroids.blocks.p; a.dq = dq; a.dim = dim; a.Q = Qd + q0 * dim; a.nq = (uint32_t)m;
+    a.K = 1; a.nvec = (uint32_t)nlists; a.S = S; a.bps = bps;
+    a.dump_keys = ws.sort_keys.p; a.dump_row = Lc;
+    VI_TRY(launch_scan(a, qg, ix.order, true, (uint32_t)((m + qg - 1) / qg) * S, st));
+    VI_TRY(sort_rows(ws.sort_keys.p, m, logLc, st));
+    hipLaunchKernelGGL(take_probes_kernel, dim3((uint32_t)((m * P + 255) / 256)), dim3(256), 0, st, ws.sort_keys.p,
+                       logLc, (uint32_t)m, P, ws.probes.p + q0 * P);
+    VI_HIP(hipGetLastError());
   }
-  // ---- B. shard visiting order -> candidate order of the probes ----
-  const uint32_t logLp = log2_ceil_rows(P);
-  VI_TRY(ws.order_keys.reserve(nq << logLp));
+  return VI_OK;
+}
+
+// B. shard visiting order -> candidate order of the probes (ws.gorder and the offset arrays), from ws.probes; or, with
+// `given`, from the order the caller supplied (already in ws.gorder)
+vi_status generic_candidate_order(const DeviceIndex &ix, uint64_t nq, uint32_t P, bool given, hipStream_t st) {
+  SearchWorkspace &ws = ix.cur().ws;
   VI_TRY(ws.gprobe.reserve(nq * P));
   VI_TRY(ws.off_by_g.reserve(nq * P));
   VI_TRY(ws.off_by_rank.reserve(nq * P));
   VI_TRY(ws.total.reserve(nq));
+  if (given) {
+    VI_TRY(ws.probe_flag.reserve(1));
+    VI_HIP(hipMemsetAsync(ws.probe_flag.p, 0, 4, st));
+    hipLaunchKernelGGL(validate_order_kernel, dim3((uint32_t)nq), dim3(256), ((P + 31u) / 32u) * 4u, st, ws.probes.p, ws.gorder.p, P,
+                       ws.probe_flag.p);
+    VI_HIP(hipGetLastError());
+    uint32_t bad = 0;
+    VI_HIP(hipMemcpyAsync(&bad, ws.probe_flag.p, 4, hipMemcpyDeviceToHost, st));
+    VI_HIP(hipStreamSynchronize(st));
+    if (bad) return fail(VI_ERR_INVALID_INPUT, "probe order: the ranks of a query's probes must be distinct and below n_probe_eff");
+    VI_HIP(hipMemsetAsync(ws.gprobe.p, 0xFF, nq * P * sizeof(uint32_t), st));
+    VI_HIP(hipMemsetAsync(ws.off_by_rank.p, 0, nq * P * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(offsets_from_order_kernel, dim3((uint32_t)((nq + 63) / 64)), dim3(64), 0, st, ws.probes.p, ws.gorder.p,
+                       ix.list_len.p, (uint32_t)nq, P, ws.gprobe.p, ws.off_by_g.p, ws.off_by_rank.p, ws.total.p);
+    VI_HIP(hipGetLastError());
+    return VI_OK;
+  }
+  const uint32_t logLp = log2_ceil_rows(P);
+  VI_TRY(ws.order_keys.reserve(nq << logLp));
   hipLaunchKernelGGL(shard_order_keys_kernel, dim3((uint32_t)nq), dim3(256), std::max<uint64_t>(1, ix.nshards) * 4, st,
                      ws.probes.p, ix.list_shard.p, P, logLp, (uint32_t)ix.nshards, ws.order_keys.p);
   VI_HIP(hipGetLastError());
@@ -247,6 +303,33 @@ vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, ui
                      ws.probes.p, ix.list_len.p, (uint32_t)nq, P, ws.gprobe.p, ws.off_by_g.p, ws.off_by_rank.p,
                      ws.gorder.p, ws.total.p);
   VI_HIP(hipGetLastError());
+  return VI_OK;
+}
+
+}  // namespace
+
+// the coarse step alone for any n_probe (probe export of the multi-GPU protocol): ws.probes / ws.gorder
+vi_status generic_probe_export(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st) {
+  if (ix.nshards > 24576) return fail(VI_ERR_OTHER, "generic path supports at most 24576 shards");
+  VI_TRY(generic_coarse(ix, Qd, nq, P, st));
+  return generic_candidate_order(ix, nq, P, false, st);
+}
+
+vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
+                                      float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
+                                      hipStream_t st, const uint32_t *probes_in, const uint32_t *order_in) {
+  SearchWorkspace &ws = ix.cur().ws;
+  const uint32_t dim = ix.dim, dq = ix.dq;
+  const uint64_t nlists = ix.nlists;
+  if (ix.nshards > 24576) return fail(VI_ERR_OTHER, "generic path supports at most 24576 shards");
+  vi_search_stats &stt = ix.cur().stats;
+  if (probes_in) {  // probe lists computed elsewhere: validated, then placed by the given order
+    VI_TRY(adopt_probes(ix, nq, P, probes_in, order_in, false, st));
+    VI_TRY(generic_candidate_order(ix, nq, P, true, st));
+  } else {
+    VI_TRY(generic_coarse(ix, Qd, nq, P, st));
+    VI_TRY(generic_candidate_order(ix, nq, P, false, st));
+  }
   std::vector<uint64_t> h_total(nq);
   VI_HIP(hipMemcpyAsync(h_total.data(), ws.total.p, nq * 8, hipMemcpyDeviceToHost, st));
   VI_HIP(hipStreamSynchronize(st));

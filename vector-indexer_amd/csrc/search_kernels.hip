@@ -1091,7 +1091,8 @@ bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint
 
 vi_status device_index_search_generic(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P,
                                       float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts,
-                                      hipStream_t st);
+                                      hipStream_t st, const uint32_t *probes_in, const uint32_t *order_in);
+vi_status generic_probe_export(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // pipeline stages
@@ -1326,17 +1327,16 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   const bool use_filter = !generic && filter_path_applicable(ix, nq, k, P);
   const bool timing = ix.timing && !generic;
   if (io.probes_out) {  // coarse step only (multi-GPU: this rank's slice of the queries)
-    if (P > kMaxSelect) return fail(VI_ERR_INVALID_INPUT, "probe export supports n_probe <= 64");
-    if (filter_path_applicable(ix, nq, 1, P) && nq >= 256 && nlists >= 1024) VI_TRY(coarse_only_filter(ix, Qd, nq, P, st));
+    if (P > kMaxSelect) VI_TRY(generic_probe_export(ix, Qd, nq, P, st));  // any n_probe: every coarse distance, sorted
+    else if (filter_path_applicable(ix, nq, 1, P) && nq >= 256 && nlists >= 1024) VI_TRY(coarse_only_filter(ix, Qd, nq, P, st));
     else VI_TRY(stage_coarse(ix, Qd, nq, P, st));
     VI_HIP(hipMemcpyAsync(io.probes_out, ws.probes.p, nq * P * 4, hipMemcpyDeviceToDevice, st));
     VI_HIP(hipMemcpyAsync(io.order_out, ws.gorder.p, nq * P * 4, hipMemcpyDeviceToDevice, st));
     VI_HIP(hipStreamSynchronize(st));
     return VI_OK;
   }
-  if (io.probes_in && generic) return fail(VI_ERR_INVALID_INPUT, "given probes support k and n_probe <= 64");
-  if (generic) {
-    VI_TRY(device_index_search_generic(ix, Qd, nq, k, P, Dd, Id, Td, slots, ws.counts.p, st));
+  if (generic) {  // (k > 128 or n_probe > 64, with the caller's probe lists too)
+    VI_TRY(device_index_search_generic(ix, Qd, nq, k, P, Dd, Id, Td, slots, ws.counts.p, st, io.probes_in, io.order_in));
   } else if (use_filter) {
     VI_TRY(search_filter_pipeline(ix, Qd, nq, k, P, K, Dd, Id, Td, slots, ws.counts.p, st, timing, io.probes_in, io.order_in));
   } else {
