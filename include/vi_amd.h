@@ -139,7 +139,8 @@ vi_status vi_kmeans_parallel_device(int32_t device, const float *X_dev, uint64_t
  *   assignment vi_assign_device on every rank's own points (labels stay local) — the O(N k D) part.
  *   Lloyd      per iteration: vi_assign_device, vi_kmeans_partial_sums_device (this rank's sums k x d and counts k),
  *              all-reduce(sum) of both, vi_kmeans_finish_update_device (means, RMS movement, empty clusters);
- *              empty clusters are re-seeded with rows drawn by rank 0's vi_rng and fetched like the training rows.
+ *              empty clusters are re-seeded with rows drawn from a vi_rng stream every rank replays (same seed, same
+ *              draws) and fetched like the training rows.
  *              Sums combined over ranks associate differently from the reference's single pass: centroids agree
  *              to rounding (compare with a tolerance), labels of the first iteration exactly. */
 typedef struct vi_row_source {
@@ -231,7 +232,12 @@ vi_status vi_indexer_load(const vi_config *cfg, vi_indexer **out);
 /* VectorIndexer::build_from_records(self, records) — src/api.rs:115-146.
  * values: n x dimension; ext_ids: n (NULL => 0..n-1); timestamps: n (NULL or 0 => now).
  * dims (optional, n): per-record length, to reproduce the "vector dimension mismatch at
- * index {i}" error (api.rs:122-133); NULL => all equal cfg.dimension. */
+ * index {i}" error (api.rs:122-133); NULL => all equal cfg.dimension.
+ * Device memory: the build keeps the uploaded points (4 n D bytes, + 16 n for ids and timestamps when given) resident
+ * until the searchable index built from them (another 4 n D for the blocks + 4 n D of bf16 images, + 1 n D for 8-bit data)
+ * is complete: its peak is about twice what vi_indexer_load of the same index needs; the grouping sort adds 16 n bytes
+ * and the largest shard's staging image transiently.  A data set that fills more than ~40 % of HBM should be built in
+ * parts or loaded from shard files written elsewhere. */
 vi_status vi_indexer_build_from_records(vi_indexer *ix, const uint64_t *ext_ids, const float *values,
                                         const uint64_t *timestamps, const uint32_t *dims, uint64_t n);
 /* VectorIndexer::build_from_vector_file(self, path) — src/api.rs:149-186 */

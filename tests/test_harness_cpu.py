@@ -107,3 +107,23 @@ def test_adapter_and_result_files(tmp_path):
     assert back[0]["search_results"]["nprobe=1"]["qps"] == 2000.0
     md = open(tmp_path / "faiss_bench_results.md").read()
     assert "| 1 | 0.2500 | 0.5000 | - | 0.500 | 2000.0 |" in md and "Build time: 1.50s" in md
+
+
+def test_load_local_data_slices_and_validates(tmp_path):
+    """load_local_npy_data (bench_all_ivf.py:175-260): n / nq / k slicing, dimension check, gt width check, gt recomputed
+    when it names rows beyond the slice"""
+    from vector_indexer_py import harness as H
+    rng = np.random.default_rng(3)
+    xb, xq = rng.standard_normal((300, 8)).astype(np.float32), rng.standard_normal((40, 8)).astype(np.float32)
+    gt = H.exact_ground_truth(xb, xq, 10)
+    np.save(tmp_path / "xb.npy", xb), np.save(tmp_path / "xq.npy", xq), np.save(tmp_path / "gt.npy", gt)
+    np.save(tmp_path / "xq5.npy", xq[:, :5].copy()), np.save(tmp_path / "gt3.npy", gt[:, :3].copy())
+    b, q, g = H.load_local_data(str(tmp_path / "xb.npy"), str(tmp_path / "xq.npy"), str(tmp_path / "gt.npy"), 300, 25, 7)
+    assert b.shape == (300, 8) and q.shape == (25, 8) and (g == gt[:25, :7]).all()
+    # sliced base set: the stored gt names rows >= 120 -> recomputed for the slice
+    b, q, g = H.load_local_data(str(tmp_path / "xb.npy"), str(tmp_path / "xq.npy"), str(tmp_path / "gt.npy"), 120, 40, 5)
+    assert b.shape == (120, 8) and g.max() < 120 and (g == H.exact_ground_truth(xb[:120], xq, 5)).all()
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        H.load_local_data(str(tmp_path / "xb.npy"), str(tmp_path / "xq5.npy"), None, 300, 40, 5)
+    with pytest.raises(ValueError, match="only 3 neighbors"):
+        H.load_local_data(str(tmp_path / "xb.npy"), str(tmp_path / "xq.npy"), str(tmp_path / "gt3.npy"), 300, 40, 5)

@@ -180,6 +180,30 @@ def test_sharded_lloyd_all_reduce(world):
             hip.close()
 
 
+def test_sharded_lloyd_with_ranks_that_own_no_points():
+    """n = 9 points over 8 ranks (two per rank: ranks 5..7 are empty): an empty rank contributes zero sums and counts to
+    the all-reduce instead of failing the loop (vi_kmeans_partial_sums_device with n_local = 0)"""
+    n, d, k, world = 9, 8, 3, 8
+    X = clustered(n, d, 3, 5)
+    Cs, ls, its = vip.kmeans_parallel(X, k, 6, seed=9, mode=vip.VI_ASSIGN_EXACT)
+
+    def fn(engine, comm, pts, hip):
+        Cb, Lb, it = VD.kmeans_parallel_sharded(engine, comm, pts, k, 6, seed=9, mode=vip.VI_ASSIGN_EXACT)
+        return hip.download(Cb.ptr, (k, d), np.float32), hip.download(Lb.ptr, (max(pts.n_local, 1),), np.uint32)[:pts.n_local], it
+    res, hip = run_ranks(world, X, fn)
+    try:
+        assert [r[1].size for r in res] == [2, 2, 2, 2, 1, 0, 0, 0]
+        for Cr, _, it in res:
+            assert (Cr.view(np.uint32) == res[0][0].view(np.uint32)).all()
+        lab = np.concatenate([r[1] for r in res])
+
+        def inertia(Cn, l):
+            return float(((X - Cn[l.astype(np.int64)]) ** 2).sum())
+        assert inertia(res[0][0], lab) <= inertia(Cs, ls) * (1 + 1e-3) + 1e-6
+    finally:
+        hip.close()
+
+
 def test_rng_stream_is_the_oracles():
     """vi_rng (rand 0.8.5 StdRng restated in rng.hpp) draws what the oracle's restatement draws (itself pinned to the
     golden vectors of tests/golden/rng.json by test_oracle_golden.py)"""

@@ -722,7 +722,8 @@ vi_status mfma_assign_device(const float *Xd, uint64_t n, const float *Cd, uint6
   }
   // tier 0: the hi-only candidate sweep (one MFMA per product) + exact evaluation of the listed candidates; what it
   // cannot decide (list overflow, NaN rows) continues through the tiers below.  VI_ASSIGN_CAND=0: start at bf16 x 3.
-  static const bool cand_on = [] { const char *e = getenv("VI_ASSIGN_CAND"); return !(e && *e == '0'); }();
+  const char *cand_env = getenv("VI_ASSIGN_CAND");
+  const bool cand_on = !(cand_env && *cand_env == '0');
   const bool use_cand = bf16 && cand_on && k >= 64ull * 8 * kCandWarmTiles;
   CandArgs ca{};
   if (use_cand) {

@@ -2126,11 +2126,10 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       WideArgs a{(const uint4 *)ix.lists_bf16.p, ix.xnorm_img.p, (const uint4 *)ws.qimg.p, nc, ix.list_first_block.p, ix.list_len.p,
                  ws.item_start.p, ws.seg_start.p, ws.pairs.p, ws.item_list.p, P, segb0, ws.qoff.p, ws.pair_rel.p, ws.tile_start.p,
                  (float4 *)ws.gval.p, ws.gpos.p, (float4 *)ws.brec.p};
-      static const bool attr = [] {
-        return hipFuncSetAttribute((const void *)rank_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kWideLdsFloats * (int)sizeof(float)) == hipSuccess;
-      }();
-      if (!attr) return fail(VI_ERR_DEVICE, "cannot reserve %d bytes of LDS for the wide rank kernel", kWideLdsFloats * 4);
+      // (set on the device that launches, every time: a process may hold indexes on several GPUs)
+      if (hipFuncSetAttribute((const void *)rank_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kWideLdsFloats * (int)sizeof(float)) != hipSuccess)
+        return fail(VI_ERR_DEVICE, "cannot reserve %d bytes of LDS for the wide rank kernel", kWideLdsFloats * 4);
       VI_TRY(start_rank_clock());
       hipLaunchKernelGGL(rank_wide_kernel, dim3(nitems), dim3(256), kWideLdsFloats * sizeof(float), st, a);
     }

@@ -463,14 +463,21 @@ vi_status launch_one(const RankStreamArgs &a, uint32_t nitems, hipStream_t st) {
   // LDS: the query image, the waves' minima of an item (1 KB per query tile), the item indices
   const size_t img = (size_t)StreamLayout<2 * NC * (QLO ? 2 : 1)>::RP * (32 * NU) * 16;
   const size_t lds = img * (stream_double_buffered((int)img) ? 2 : 1) + 2 * (size_t)NU * 1024 + 16;
-  static const bool ok = hipFuncSetAttribute((const void *)rank_stream_kernel<NC, RANK, QLO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds) == hipSuccess;
-  if (!ok) return fail(VI_ERR_DEVICE, "cannot reserve %zu bytes of LDS for the rank kernel", lds);
-  static const uint32_t cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return (uint32_t)n;
-  }();
+  // per device (a process may hold indexes on several GPUs: the attribute and the CU count belong to the device that launches)
+  constexpr int kMaxDev = 64;
+  static uint32_t cus_of[kMaxDev];  // 0 = not yet prepared on that device
+  int dev = 0;
+  VI_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDev) return fail(VI_ERR_DEVICE, "device ordinal %d out of range", dev);
+  uint32_t cus = __atomic_load_n(&cus_of[dev], __ATOMIC_ACQUIRE);
+  if (cus == 0) {
+    if (hipFuncSetAttribute((const void *)rank_stream_kernel<NC, RANK, QLO, NU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(VI_ERR_DEVICE, "cannot reserve %zu bytes of LDS for the rank kernel", lds);
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = (uint32_t)n;
+    __atomic_store_n(&cus_of[dev], cus, __ATOMIC_RELEASE);
+  }
   uint32_t per_cu = lds > 80 * 1024 ? 1u : 2u;  // persistent workgroups: as many as fit on the chip at once
   if (const char *e = getenv("VI_STREAM_WGS_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));  // (experiment)
   if (a.prof) {

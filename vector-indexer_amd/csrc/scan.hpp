@@ -13,10 +13,10 @@ namespace vi {
 // the scan kernel always consumes whole groups of 4 quads
 inline uint32_t layout_dq(uint32_t dim) { return ((dim + 15) / 16) * 4; }
 
-// (query, probe) pairs are counted / scattered per (list, query & 7): hot lists are probed by thousands of
+// (query, probe) pairs are counted / scattered per (list, query & (kSubBins - 1)): hot lists are probed by thousands of
 // queries of a batch and a single counter per list would serialise their atomics
 constexpr uint32_t kSubBins = 32;
-// counter of (list l, sub-bin s).  Sub-bin major, every sub-bin's row on cache lines of its own: the 8 counters of a
+// counter of (list l, sub-bin s).  Sub-bin major, every sub-bin's row on cache lines of its own: the 32 counters of a
 // hot list must not share a line — atomics on one line execute one after the other at its L2 channel (the hottest lists
 // of a batch are probed by every query: 10 000 atomics on one line were 0.15 ms of the coarse select)
 __host__ __device__ inline uint32_t subbin_stride(uint32_t nlists) { return (nlists + 31u) & ~31u; }

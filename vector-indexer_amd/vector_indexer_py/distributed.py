@@ -275,7 +275,8 @@ def kmeans_parallel_sharded(engine, comm, pts, k, max_iters, thr=None, seed=42, 
     rng = engine.rng(seed)  # handle_empty_clusters draws from a stream of its own (kmeans.rs:31)
     it = 0
     while it < max_iters:
-        engine.assign(pts.ptr, pts.n_local, d, Cb.ptr, k, seed, mode, Lb.ptr)
+        if pts.n_local:  # (a rank without points — world > n, or an uneven split — contributes zero sums)
+            engine.assign(pts.ptr, pts.n_local, d, Cb.ptr, k, seed, mode, Lb.ptr)
         engine.partial_sums(pts.ptr, pts.n_local, d, Lb.ptr, k, Sb.ptr, Nb.ptr)
         comm.all_reduce_sum(Sb, k * d, "f32")
         comm.all_reduce_sum(Nb, k, "u32")

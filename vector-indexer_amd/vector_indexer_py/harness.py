@@ -76,15 +76,36 @@ def exact_ground_truth(xb: np.ndarray, xq: np.ndarray, k: int) -> np.ndarray:
     """exact k nearest by squared L2 (float64 brute force, blocked); ties by lower index"""
     k = min(k, xb.shape[0])
     out = np.empty((xq.shape[0], k), dtype=np.int64)
-    bn = (xb.astype(np.float64) ** 2).sum(1)
+    xbt = np.ascontiguousarray(xb.T, dtype=np.float64)  # (once: the cast is 8 N D bytes)
+    bn = (xbt ** 2).sum(0)
     for s in range(0, xq.shape[0], 256):
         q = xq[s:s + 256].astype(np.float64)
-        dist = (q ** 2).sum(1)[:, None] - 2.0 * (q @ xb.T.astype(np.float64)) + bn[None, :]
+        dist = (q ** 2).sum(1)[:, None] - 2.0 * (q @ xbt) + bn[None, :]
         part = np.argpartition(dist, k - 1, axis=1)[:, :k] if k < xb.shape[0] else np.tile(np.arange(k), (q.shape[0], 1))
         pd = np.take_along_axis(dist, part, axis=1)
         order = np.lexsort((part, pd), axis=1)
         out[s:s + 256] = np.take_along_axis(part, order, axis=1)
     return out
+
+
+def load_local_data(xb_path: str, xq_path: str, gt_path: Optional[str], n: int, nq: int, k: int):
+    """load_local_npy_data (bench_all_ivf.py:175-260): the files sliced to (n, nq, k); dimensions must agree; a ground
+    truth with fewer than k columns is an error; one that names rows beyond the sliced xb (or none at all) is recomputed
+    exactly"""
+    xb, xq = load_vectors(xb_path, n), load_vectors(xq_path, nq)
+    if xb.shape[1] != xq.shape[1]:
+        raise ValueError(f"Dimension mismatch: xb has d={xb.shape[1]}, xq has d={xq.shape[1]}")
+    gt = None
+    if gt_path:
+        gt = load_groundtruth(gt_path, xq.shape[0])
+        if gt.shape[1] < k:
+            raise ValueError(f"Ground truth has only {gt.shape[1]} neighbors per query, but k={k} was requested")
+        gt = np.ascontiguousarray(gt[:xq.shape[0], :k])
+        if gt.size and int(gt.max()) >= xb.shape[0]:
+            gt = None  # (written for a larger base set: recompute for the slice, as the reference does)
+    if gt is None:
+        gt = exact_ground_truth(xb, xq, k)
+    return xb, xq, gt
 
 
 def synthetic_dataset(n: int, d: int, nq: int, k: int, seed: int = 42) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -196,13 +217,14 @@ def main(argv=None):
     ap.add_argument("--min-test-duration", type=float, default=2.0)
     ap.add_argument("--nlist", type=int, default=0, help="0 = the reference's calculate_num_clusters(n)")
     ap.add_argument("--xb-path"), ap.add_argument("--xq-path"), ap.add_argument("--gt-path")
-    ap.add_argument("--max-rows", type=int, default=None)
+    ap.add_argument("--max-rows", type=int, default=None, help="cap on the rows read from --xb-path (in addition to --n)")
     ap.add_argument("--output-dir", default="bench_results")
     ap.add_argument("--work-dir", default=None)
     a = ap.parse_args(argv)
     if a.xb_path:
-        xb, xq = load_vectors(a.xb_path, a.max_rows), load_vectors(a.xq_path)
-        gt = load_groundtruth(a.gt_path) if a.gt_path else exact_ground_truth(xb, xq, a.k)
+        if not a.xq_path:
+            raise SystemExit("--xb-path needs --xq-path")
+        xb, xq, gt = load_local_data(a.xb_path, a.xq_path, a.gt_path, min(a.n, a.max_rows) if a.max_rows else a.n, a.nq, a.k)
     else:
         xb, xq, gt = synthetic_dataset(a.n, a.d, a.nq, a.k, a.seed)
     res = run(xb, xq, gt, a.k, [int(p) for p in a.nprobe.split(",")], a.min_test_duration, a.work_dir, a.nlist)
