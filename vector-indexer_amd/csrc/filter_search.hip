@@ -1051,6 +1051,33 @@ __device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *x
   return acc;
 }
 
+// 8-bit descriptors AND an integer-valued query in 0..255 (SIFT queries are): every term (q - x)^2 of the reference's
+// sum (src/utils.rs:28-30) is an integer <= 255^2 and every partial sum an integer <= D 255^2 < 2^24 (D <= 256), so the
+// sequential f32 sum never rounds: its value IS the integer sum, whatever the order.  It is formed with byte dot
+// products: |q|^2 + |x|^2 - 2 q.x, four dimensions per v_dot4_u32_u8 — 90 instructions per distance instead of 512.
+// qb: the query as bytes (LDS, D / 4 words, zero padded to whole 16-byte pieces); qn = |q|^2.
+__device__ __forceinline__ float exact_pair_u8_int(const uint32_t *qb, uint32_t qn, const uint4 *xb, uint32_t dim) {
+  const uint32_t npiece = (dim + 15u) >> 4;
+  uint32_t dot = 0u, xx = 0u;
+  auto piece = [&](const uint4 &x, uint32_t p) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(qb + 4 * p);
+    dot = __builtin_amdgcn_udot4(q.x, x.x, dot, false); xx = __builtin_amdgcn_udot4(x.x, x.x, xx, false);
+    dot = __builtin_amdgcn_udot4(q.y, x.y, dot, false); xx = __builtin_amdgcn_udot4(x.y, x.y, xx, false);
+    dot = __builtin_amdgcn_udot4(q.z, x.z, dot, false); xx = __builtin_amdgcn_udot4(x.z, x.z, xx, false);
+    dot = __builtin_amdgcn_udot4(q.w, x.w, dot, false); xx = __builtin_amdgcn_udot4(x.w, x.w, xx, false);
+  };
+  uint32_t p = 0;
+  for (; p + 8 <= npiece; p += 8) {
+    uint4 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(x[i], p + i);
+  }
+  for (; p < npiece; ++p) piece(xb[(size_t)p * kWave], p);
+  return (float)(qn + xx - 2u * dot);  // (an integer below 2^24: exact)
+}
+
 // The select kernels are latency-sensitive code executed once per query; inlining the two heavy pieces at
 // every call site made them ~150 KB each and instruction-fetch bound.  They are real functions with their state
 // passed and returned in registers.
@@ -1075,6 +1102,15 @@ __device__ __attribute__((noinline)) Top exact_batch_u8_fn(Top sel, const float 
                                                            int K) {
   float d = INFINITY;
   if (live) d = exact_pair_u8(qrow, xb, dim);
+  sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
+}
+
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_u8_int_fn(Top sel, const uint32_t *qb, uint32_t qn, const uint4 *xb, uint32_t dim, bool live,
+                                                               uint32_t key, int K) {
+  float d = INFINITY;
+  if (live) d = exact_pair_u8_int(qb, qn, xb, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
   return sel;
 }
@@ -1115,7 +1151,7 @@ constexpr uint32_t kCacheG = 256;      // group records (values + probe/segment/
 template <class Top>
 __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, size_t gbase, uint32_t G, uint32_t P,
                                             const ProbeRegs &pr, uint32_t K, int lane, uint32_t *pick, float4 *tcache,
-                                            uint32_t *lcache, float *qlds, Top &sel) {
+                                            uint32_t *lcache, float *qlds, Top &sel, uint32_t *qbytes = nullptr) {
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1123,13 +1159,33 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   float qn = 0.0f;
+  bool q_bytes = c.u8_nat != nullptr && qbytes != nullptr && c.dim <= 256u;  // -> the query is integer-valued in 0..255
   for (uint32_t e = lane; e < c.dim; e += kWave) {  // the query row: into LDS for the exact evaluations, and its norm
     const float v = c.Q[(size_t)q * c.dim + e];
     qlds[e] = v;
     qn += v * v;
+    q_bytes = q_bytes && v >= 0.0f && v <= 255.0f && v == floorf(v);
   }
+  q_bytes = __ballot(!q_bytes) == 0ull;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  uint32_t qn_int = 0u;
+  if (q_bytes) {  // the query as bytes, zero padded to whole 16-byte pieces (exact_pair_u8_int), and |q|^2 as an integer
+    const uint32_t nw = ((c.dim + 15u) >> 4) * 4u;
+    for (uint32_t w = lane; w < nw; w += kWave) {
+      uint32_t word = 0u;
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t e = 4u * w + b;
+        const uint32_t v = e < c.dim ? (uint32_t)c.Q[(size_t)q * c.dim + e] : 0u;
+        word |= v << (8u * b);
+        qn_int += v * v;
+      }
+      qbytes[w] = word;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qn_int += (uint32_t)__shfl_xor((int)qn_int, o);
+  }
   const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
   // a query so large that the rank arithmetic may have overflowed (inf - inf = NaN, and NaN fails every guard
   // below): trust no rank value, re-evaluate everything the query probes
@@ -1150,7 +1206,10 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     const uint32_t len = (uint32_t)__shfl((int)pr.len, (int)r);
     live = live && pos < len && !(c.xmode & 1u);
     n_exact += (uint32_t)__popcll(__ballot(live));
-    if (c.u8_nat)
+    if (c.u8_nat && q_bytes)
+      sel = exact_batch_u8_int_fn(sel, qbytes, qn_int, c.u8_nat + ((size_t)(fb + (live ? pos : 0u) / kWave) * (c.dq / 4)) * kWave + (pos % kWave),
+                                  c.dim, live, (g << kPosBits) | pos, (int)K);
+    else if (c.u8_nat)
       sel = exact_batch_u8_fn(sel, qrow, c.u8_nat + ((size_t)(fb + (live ? pos : 0u) / kWave) * (c.dq / 4)) * kWave + (pos % kWave), c.dim,
                               live, (g << kPosBits) | pos, (int)K);
     else if (c.hi_nat)
@@ -1283,18 +1342,68 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   bool any_full = false;
   {
     s1.init();
-    for (uint32_t gb = 0; gb < G; gb += kWave) {
-      const uint32_t gidx = gb + lane;
-      const bool live = gidx < G;
-      s1 = offer_bulk_fn(s1, group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
+    // The K-th smallest of the 4 G recorded values, with its keys.  Offering all of them costs a 64-lane sort per 64 values
+    // (16 sorts at G = 256).  Instead: every lane's smallest group minimum belongs to a different sub-block, so the K-th
+    // smallest of the 64 lane minima (ONE sort) bounds the K-th smallest of all; the values at or below that bound —
+    // K to 2 K of them as a rule — are compacted through LDS and offered in one or two rounds.
+    float U = INFINITY;
+    if (K <= 64u) {
+      float lm = INFINITY;
+      for (uint32_t gb = 0; gb < G; gb += kWave) {
+        const uint32_t gidx = gb + lane;
+        lm = fminf(lm, group_values(gidx, gidx < G).x);
+      }
+      uint64_t kk = pack_key(lm, (uint32_t)lane);
+      wave_sort_u64(kk, lane);
+      U = sortable_f32((uint32_t)(readlane_u64(kk, (int)K - 1) >> 32));  // (+inf or NaN: no bound, everything is offered)
     }
-    for (uint32_t gb = 0; gb < G; gb += kWave) {
-      const uint32_t gidx = gb + lane;
-      const bool live = gidx < G;
-      const float4 T = group_values(gidx, live);
-      s1 = offer_bulk_fn(s1, T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
-      s1 = offer_bulk_fn(s1, T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
-      s1 = offer_bulk_fn(s1, T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
+    uint32_t ncand = 0;
+    bool overflow = !(U < INFINITY);
+    if (!overflow) {
+      for (uint32_t gb = 0; gb < G && !overflow; gb += kWave) {
+        const uint32_t gidx = gb + lane;
+        const bool live = gidx < G;
+        const float4 T = group_values(gidx, live);
+        const float tv[4] = {T.x, T.y, T.z, T.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const bool pass = live && !(tv[j] > U);
+          const uint64_t m = __ballot(pass);
+          if (!m) continue;
+          const uint32_t cnt = (uint32_t)__popcll(m);
+          if (ncand + cnt > kPickCap / 2u) { overflow = true; break; }
+          if (pass) {
+            const uint32_t at = ncand + (uint32_t)__popcll(m & below);
+            pick[2u * at] = __float_as_uint(tv[j]);
+            pick[2u * at + 1u] = 4u * gidx + j;
+          }
+          ncand += cnt;
+        }
+      }
+      lds_sync();
+    }
+    if (!overflow) {
+      for (uint32_t c0 = 0; c0 < ncand; c0 += kWave) {
+        const bool live = c0 + lane < ncand;
+        const float v = live ? __uint_as_float(pick[2u * (c0 + lane)]) : INFINITY;
+        s1 = offer_bulk_fn(s1, v, live ? pick[2u * (c0 + lane) + 1u] : kNoPos, (int)K);
+      }
+      lds_sync();  // (pick is reused by the stages below)
+    } else {
+      s1.init();
+      for (uint32_t gb = 0; gb < G; gb += kWave) {
+        const uint32_t gidx = gb + lane;
+        const bool live = gidx < G;
+        s1 = offer_bulk_fn(s1, group_values(gidx, live).x, live ? 4u * gidx : kNoPos, (int)K);
+      }
+      for (uint32_t gb = 0; gb < G; gb += kWave) {
+        const uint32_t gidx = gb + lane;
+        const bool live = gidx < G;
+        const float4 T = group_values(gidx, live);
+        s1 = offer_bulk_fn(s1, T.y, live ? 4u * gidx + 1u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, T.z, live ? 4u * gidx + 2u : kNoPos, (int)K);
+        s1 = offer_bulk_fn(s1, T.w, live ? 4u * gidx + 3u : kNoPos, (int)K);
+      }
     }
     thr = threshold_of(s1.kth((int)K));
     for (uint32_t gb = 0; gb < G; gb += kWave) {  // is any group's 4th value at or below it?
@@ -1368,9 +1477,10 @@ struct SelectArgs {
 
 // one wave per query: top-k over its probed lists in the reference's stable order (ivf_index.rs:264-274)
 template <class Top>
-__global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
+__global__ void __launch_bounds__(256, 4) select_kernel(SelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
+  __shared__ __attribute__((aligned(16))) uint32_t s_qbytes[4][64];  // the 4 queries as bytes (8-bit lists, D <= 256)
   extern __shared__ __attribute__((aligned(16))) float s_qrows[];  // the 4 query rows of the workgroup: 4 x dim floats
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
@@ -1393,7 +1503,7 @@ __global__ void __launch_bounds__(256) select_kernel(SelectArgs a) {
   }
   Top sel;
   select_body<Top>(a.c, q, a.qoff[q], a.qtot[q], a.P, pr, a.k, lane, s_pick[wave], s_tcache[wave],
-                   s_lcache[wave], s_qrows + (size_t)wave * a.c.dim, sel);
+                   s_lcache[wave], s_qrows + (size_t)wave * a.c.dim, sel, s_qbytes[wave]);
   // entry e of lane i holds result 64e + i: map the candidate-order rank g back to the probe rank r
   uint32_t found = 0;
 #pragma unroll
@@ -1441,7 +1551,7 @@ struct CoarseSelectArgs {
 
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
 // sort, ivf_index.rs:205-220), then shard visiting order + histogram as in coarse_merge_kernel
-__global__ void __launch_bounds__(256) coarse_select_kernel(CoarseSelectArgs a) {
+__global__ void __launch_bounds__(256, 4) coarse_select_kernel(CoarseSelectArgs a) {
   __shared__ uint32_t s_pick[4][kPickCap], s_lcache[4][kCacheG];
   __shared__ float4 s_tcache[4][kCacheG];
   __shared__ __attribute__((aligned(16))) float s_q[4][kNarrowDim];  // (the coarse step runs here only for D <= 128)
