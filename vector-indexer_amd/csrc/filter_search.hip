@@ -58,7 +58,9 @@ vi_status stage_coarse(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint
 vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uint32_t *probes_in, const uint32_t *order_in,
                        bool histogram, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[14], hipStream_t st, bool histogram_done);
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot = nullptr,
+                          uint32_t *qoff = nullptr);
+bool grouping_fuses_query_offsets(const DeviceIndex &ix);
 
 namespace {
 
@@ -2162,7 +2164,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       hipLaunchKernelGGL(pair_groups_kernel, dim3((uint32_t)((nq + 255) / 256)), dim3(256), 0, st, ws.probes.p,
                          ix.list_len.p, (uint32_t)nq, P, segb0, ws.pair_rel.p, ws.qtot.p);
     }
-    hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
+    // (the grouping's scan kernel scans the record offsets too, as a second workgroup)
+    if (!grouping_fuses_query_offsets(ix)) hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(1024), 0, st, ws.qtot.p, (uint32_t)nq, ws.qoff.p);
     VI_HIP(hipGetLastError());
   }
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[1], st));
@@ -2197,7 +2200,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     const char *e = getenv("VI_STREAM_GQ");
     gq = e && atoi(e) == 256 && ws.queries_hi_only ? 256u : 128u;
   }
-  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true));
+  const bool fuse_q = grouping_fuses_query_offsets(ix);
+  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true, fuse_q ? ws.qtot.p : nullptr, fuse_q ? ws.qoff.p : nullptr));
   {
     const double fill128 = hstats[12] ? (double)hstats[0] / ((double)hstats[12] * 128.0 * 64.0) : 0.0;
     const uint32_t next = fill128 >= 0.3 ? 128u : 32u;

@@ -471,6 +471,107 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
   }
 }
 
+// group_scan_kernel (workgroup 0) and the queries' record offsets (workgroup 1: exclusive scan of qtot, qoff[nq] = total)
+// in one launch: both are single-workgroup scans, independent of each other.  (Folding list_totals and cursor in as well —
+// one workgroup reading all 32 sub-bins of every list twice — was measured: the grouping took twice as long.)
+__global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt, const uint32_t *list_len, uint32_t nlists, uint32_t qg,
+                                                             uint32_t segb0, uint32_t *seg_start, uint32_t *item_start,
+                                                             uint32_t *segrun_start, uint64_t *stats, uint32_t *tile_start,
+                                                             const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
+  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  if (blockIdx.x == 1) {  // ---- query offsets ----
+    if (!qtot) return;
+    const uint32_t per = (nq + 1023) / 1024;
+    const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= o) inc += x;
+    }
+    if (lane == 63) s_seg[wave] = inc;
+    __syncthreads();
+    uint32_t w = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      if (i < wave) w += s_seg[i];
+      tot += s_seg[i];
+    }
+    uint32_t run = w + inc - sum;
+    for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
+    if (t == 0) qoff[nq] = tot;
+    return;
+  }
+  // ---- lists (cnt = the per-list totals of list_totals_kernel, which also reset the counters added to below) ----
+  const uint32_t per = (nlists + 1023) / 1024;
+  const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
+  uint32_t seg = 0, item = 0, run = 0, tile = 0;
+  unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
+  for (uint32_t l = beg; l < end; ++l) {
+    const uint32_t c = cnt[l];
+    const uint32_t len = list_len[l];
+    uint32_t segb;
+    const uint32_t ns = list_segments(len, segb0, &segb);
+    const uint32_t chunks = (c + qg - 1) / qg;
+    seg += c;
+    item += chunks * ns;
+    run += ns > 1 ? c * ns : 0u;
+    vec += (unsigned long long)c * len;
+    mtile += (unsigned long long)chunks * ((len + 63) / 64);
+    mtile128 += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);
+    tile += chunks * ns * seg_records(segb);
+    rec += 2ull * c * ns;
+  }
+  uint32_t iseg = seg, iitem = item, irun = run, itile = tile;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t a = (uint32_t)__shfl_up((int)iseg, o), b = (uint32_t)__shfl_up((int)iitem, o);
+    const uint32_t r = (uint32_t)__shfl_up((int)irun, o), tt = (uint32_t)__shfl_up((int)itile, o);
+    if (lane >= o) { iseg += a; iitem += b; irun += r; itile += tt; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vec += __shfl_xor(vec, o);
+    rec += __shfl_xor(rec, o);
+    mtile += __shfl_xor(mtile, o);
+    mtile128 += __shfl_xor(mtile128, o);
+  }
+  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
+  if (lane == 0) {
+    atomicAdd((unsigned long long *)&stats[0], vec);
+    atomicAdd((unsigned long long *)&stats[4], rec);
+    atomicAdd((unsigned long long *)&stats[3], mtile);
+    atomicAdd((unsigned long long *)&stats[12], mtile128);
+  }
+  __syncthreads();
+  uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; wtile += s_tile[w]; }
+    tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
+  }
+  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
+  for (uint32_t l = beg; l < end; ++l) {
+    uint32_t segb;
+    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
+    seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
+    if (tile_start) tile_start[l] = rt;
+    const uint32_t c = cnt[l];
+    rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
+    rt += ((c + qg - 1) / qg) * ns * seg_records(segb);
+  }
+  if (t == 0) {
+    seg_start[nlists] = tseg;
+    item_start[nlists] = titem;
+    segrun_start[nlists] = trun;
+    stats[1] = titem;
+    stats[2] = trun;
+    stats[5] = ttile;
+  }
+}
+
 // (list ids are range-checked wherever they index: a caller-supplied probe list, vi_indexer_search_probed_device, is
 // validated up front by validate_probes_kernel, and a stray word can then still not fault the GPU)
 __global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t n, uint32_t P,
@@ -1099,14 +1200,18 @@ vi_status generic_probe_export(const DeviceIndex &ix, const float *Qd, uint64_t 
 // ------------------------------------------------------------------------------------------
 // histogram (ws.cnt) -> totals -> offsets of the lists in pairs / items / records -> scatter cursors
 static vi_status launch_group_scan(const DeviceIndex &ix, uint32_t qg, uint32_t segb0, uint32_t *tile_start, hipStream_t st,
-                                   bool reset_stats = false) {
+                                   bool reset_stats = false, const uint32_t *qtot = nullptr, uint32_t nq = 0, uint32_t *qoff = nullptr) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint32_t nlists = (uint32_t)ix.nlists;
   VI_TRY(ws.list_tot.reserve(std::max<uint32_t>(1, nlists)));
   const dim3 grid((nlists + 255) / 256), block(256);
   hipLaunchKernelGGL(list_totals_kernel, grid, block, 0, st, ws.cnt.p, nlists, ws.list_tot.p, reset_stats ? ws.stats.p : nullptr);
-  hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.list_tot.p, ix.list_len.p, nlists, qg, segb0,
-                     ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p, tile_start);
+  if (qtot)  // (+ the queries' record offsets: a second workgroup of the same launch)
+    hipLaunchKernelGGL(group_prepare_kernel, dim3(2), dim3(1024), 0, st, ws.list_tot.p, ix.list_len.p, nlists, qg, segb0,
+                       ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p, tile_start, qtot, nq, qoff);
+  else
+    hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(1024), 0, st, ws.list_tot.p, ix.list_len.p, nlists, qg, segb0,
+                       ws.seg_start.p, ws.item_start.p, ws.segrun_start.p, ws.stats.p, tile_start);
   hipLaunchKernelGGL(cursor_kernel, grid, block, 0, st, ws.cnt.p, ws.seg_start.p, nlists, ws.cnt.p + subbin_words(nlists));
   VI_HIP(hipGetLastError());
   return VI_OK;
@@ -1379,8 +1484,10 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 
 // Counting sort of nq*P (query, probe) pairs by list for the generic path (the fast path folds
 // the histogram into coarse_merge_kernel).  Fills ws.{cnt,seg_start,item_start,segrun_start,pairs}.
+bool grouping_fuses_query_offsets(const DeviceIndex &) { return true; }
+
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[14], hipStream_t st, bool histogram_done) {
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot, uint32_t *qoff) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1398,7 +1505,7 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
     hipLaunchKernelGGL(histogram_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
                        (uint32_t)nlists, total, P, ws.cnt.p);
   }
-  VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st, true));
+  VI_TRY(launch_group_scan(ix, (uint32_t)qg, segb0, ws.tile_start.p, st, true, qtot, (uint32_t)nq, qoff));
   // the host waits for the counts (grid size, scratch) while the scatter runs
   // (into page-locked memory: a copy to the caller's stack array is staged by the runtime and costs a few microseconds
   // more on the one synchronisation point of the pipeline)
