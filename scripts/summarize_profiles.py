@@ -60,7 +60,7 @@ def short(n):
 
 
 # ---- headline -------------------------------------------------------------------------------------------------------
-SEARCH = r"rank_stream_kernel|filter_kernel<|select_kernel|coarse_select|group_scan|group_scatter|query_offsets|list_totals|cursor_kernel|item_desc|item_cols|split_queries|scan_kernel<\d+, 0"
+SEARCH = r"rank_stream_kernel|filter_kernel<|select_kernel|coarse_select|group_scan|group_prepare|group_scatter|query_offsets|list_totals|cursor_kernel|item_desc|item_cols|split_queries|scan_kernel<\d+, 0"
 RANK = r"rank_stream_kernel<|filter_kernel<\d+, \d+, false"
 ks = kernel_stats("head_kt", f"profiles/{tag}_headline_kernel_stats.csv")
 line = json_line(f"gpurun_out/prof_{tag}_head_kt.log")
