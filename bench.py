@@ -55,7 +55,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3    # dense f32 matrix peak: 256 CUs x 256 flop/clk x 2.4 GHz
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 matrix peak: 256 CUs x 4096 flop/clk x 2.4 GHz
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_scan_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_scan_traffic.json")
 
 
 def make_dataset(n, d, nq, seed, device):
