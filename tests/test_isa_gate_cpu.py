@@ -158,3 +158,76 @@ def test_streaming_rank_kernel_multiplies_while_the_next_tile_loads(stream_asm):
         assert steps >= 2, name   # the two halves of the unrolled tile loop
         checked += 1
     assert checked >= 8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3 kernels.  (1) the k-means candidate sweep (assign_mfma.hip): no spill in any instantiation; inside the tile loop
+# NO global store (a store would make the step's `s_waitcnt vmcnt(0)` wait for its round trip: measured 56 -> 45 ms at C3)
+# and no plain global load (the tile arrives by LDS-DMA); the MFMA chain of a step is not interrupted by a full LDS
+# drain (fragments run two chunks ahead).  (2) the big-cluster sum kernel (kmeans.hip) keeps its three register sets in
+# registers (an array of HIP's float4 struct once sat in scratch memory: 5.0 -> 1.0 ms).  (3) the select kernels' wave
+# top-K exchanges lanes with DPP / v_permlane*_swap: no ds_bpermute in the sorting network (wave_sort.hpp).
+# ---------------------------------------------------------------------------------------------------------------
+def _compile(tmp_path_factory, src):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("isa") / (os.path.basename(src) + ".s"))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"]
+    subprocess.check_call([HIPCC, *flags, "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernel_bodies(asm_text, pattern):
+    out = {}
+    for m in re.finditer(r"^(" + pattern + r"):[^\n]*\n(.*?)\n\.Lfunc_end", asm_text, re.S | re.M):
+        name, body = m.group(1), m.group(m.lastindex)
+        mm = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(.*?)\.end_amdhsa_kernel", asm_text, re.S)
+        out[name] = (body, mm.group(1) if mm else "")   # (device functions have no kernel descriptor)
+    return out
+
+
+def test_candidate_sweep_keeps_its_tile_loop_free_of_global_memory(tmp_path_factory):
+    text = _compile(tmp_path_factory, os.path.join(ROOT, "vector-indexer_amd", "csrc", "assign_mfma.hip"))
+    ks = _kernel_bodies(text, r"_ZN2vi12_GLOBAL__N_123mfma_assign_cand_kernelILi\d+EEEvNS0_8CandArgsE")
+    assert len(ks) == 8   # NC = 1 .. 8 chunks of 16 dimensions
+    for name, (body, meta) in ks.items():
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
+        lines = body.split("\n")
+        barriers = [i for i, l in enumerate(lines) if "s_barrier" in l]
+        stores = [i for i, l in enumerate(lines) if re.match(r"\s*global_store_", l)]
+        loads = [i for i, l in enumerate(lines) if re.match(r"\s*global_load_(?!lds)", l)]
+        assert any("global_load_lds_dwordx4" in l for l in lines), name
+        # (whatever shape the compiler gives the tile loop: every store comes after the last barrier — the final flush of the
+        # lists — and every plain load before the first one — the points' own values)
+        assert stores and min(stores) > barriers[-1], f"{name}: a global store inside the sweep"
+        assert loads and max(loads) < barriers[0], f"{name}: a plain global load inside the sweep"
+        assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", body)) >= 4 * int(re.search(r"ILi(\d+)E", name).group(1)), name
+    # the D = 128 instantiation: between the first and the last MFMA of a step the LDS counter is never drained to
+    # zero except at the very end (the last fragments) — i.e. the fragment reads run ahead of the chain
+    body8 = [b for n, (b, _) in ks.items() if "ILi8E" in n][0]
+    lines = block_loop(body8).split("\n")
+    mf = [i for i, l in enumerate(lines) if "v_mfma_f32_32x32x16_bf16" in l]
+    chain = lines[mf[0]:mf[31] + 1]
+    drains = [i for i, l in enumerate(chain) if re.search(r"s_waitcnt[^\n]*lgkmcnt\(0\)", l)]
+    assert all(i > len(chain) - 12 for i in drains), "the MFMA chain waits for every fragment read"
+
+
+def test_big_cluster_sums_stay_in_registers(tmp_path_factory):
+    text = _compile(tmp_path_factory, os.path.join(ROOT, "vector-indexer_amd", "csrc", "kmeans.hip"))
+    ks = _kernel_bodies(text, r"_ZN2vi12_GLOBAL__N_118segment_big_kernelE\w+")
+    assert len(ks) == 1
+    for name, (body, meta) in ks.items():
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane (the row register sets must not live in memory)"
+        assert not re.search(r"\bscratch_(load|store)", body), name
+        assert len(re.findall(r"global_load_dwordx4", body)) >= 8, name   # 16-byte row pieces
+
+
+def test_select_top_k_sorts_without_the_lds_crossbar(asm):
+    ks = _kernel_bodies(asm, r"_ZN2vi12_GLOBAL__N_113offer_bulk_fnINS_(8FastTopK|10FastTop128)EEET_S\d_fji")
+    assert len(ks) == 2
+    for name, (body, _) in ks.items():
+        assert "ds_bpermute" not in body, f"{name}: the sorting network goes through the LDS crossbar again"
+        assert "v_permlane32_swap" in body and "v_permlane16_swap" in body and "_dpp" in body, name
+        assert len(re.findall(r"v_cmp_\w+_u64", body)) >= 27, name   # one 64-bit compare per compare-exchange step

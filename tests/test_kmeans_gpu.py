@@ -199,3 +199,29 @@ def test_exact_mode_kmeans_and_build_match_oracle_force_brute(tmp_path):
     rc, Co, lo, ito = O.kmeans_mini_batch(X, 200, 30, seed=42, force_brute=True)
     Cg, lg, itg = vip.kmeans_mini_batch(X, 200, 30, seed=42, mode=vip.VI_ASSIGN_EXACT)
     assert rc == 0 and itg == ito and (bits(Cg) == bits(Co)).all() and (lg == lo).all()
+
+
+@pytest.mark.parametrize("d,kind", [(12, "gauss"), (16, "grid"), (40, "gauss"), (64, "gauss"), (72, "offset"), (100, "gauss"),
+                                    (128, "grid")])
+def test_candidate_sweep_exact_assign_equals_brute_force(d, kind):
+    """the hi-only candidate sweep (assign_mfma.hip: first tier from 8 192 centroids on) for every chunk count 1 .. 8 —
+    odd ones included, whose tile images are not a multiple of the four waves' DMA pieces — on Gaussian data, on an integer
+    grid (masses of exact ties and duplicate centroids: lowest index must win, src/kmeans.rs:364-370) and far from the
+    origin (wide margins: lists overflow into the older tiers): labels == assign_points_brute_force bit for bit"""
+    n, k = 6000, 8192 + 77
+    rng = np.random.default_rng(d)
+    if kind == "grid":
+        X = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        Cn = rng.integers(-3, 4, size=(k, d)).astype(np.float32)
+        Cn[4000:4100] = Cn[100:200]                       # duplicate centroids
+        X[:500] = Cn[rng.integers(0, k, 500)]             # points ON centroids
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Cn = rng.standard_normal((k, d)).astype(np.float32)
+        if kind == "offset":
+            X += 40.0
+            Cn += 40.0
+    want = O.assign(X, Cn, mode="brute")
+    got = vip.assign(X, Cn, mode=vip.VI_ASSIGN_EXACT)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} of {n} labels differ, first row {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"

@@ -442,7 +442,13 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
   const uint32_t steps = a.ntiles + a.warm;       // tiles 0 .. ntiles-1 (the first `warm` without listing), then 0 .. warm-1 again
   auto tile_of = [&](uint32_t s) { return s < a.ntiles ? s : s - a.ntiles; };
   auto dma_tile = [&](float *buf, uint32_t tile) {  // asm copies: see mfma_assign_bf16_kernel
-    tile_dma_image_asm<NC>(buf, a.img + tile * img_stride, a.cn + (size_t)tile * kTileC, wave, lane);
+    // 2 NC pieces of 1 KB round-robin over the four waves (2 NC need not be a multiple of 4: NC is odd for D = 16, 48, ...)
+#pragma unroll
+    for (int i = 0; i < (2 * NC + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < 2 * NC) glds16_asm(a.img + tile * img_stride + piece * 64 + lane, buf + piece * 256);
+    }
+    if (wave == 0) glds4_asm(a.cn + (size_t)tile * kTileC + lane, buf + 2 * NC * 256);
   };
   // one step: tile tile_of(s) sits in buffer s & 1; the next tile's image is requested first
   auto step = [&](uint32_t s) {
