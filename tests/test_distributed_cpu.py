@@ -194,3 +194,41 @@ def test_sharded_lloyd_exchange_gloo_world2(tmp_path):
             def inertia(Cn, l):
                 return float(((X - Cn[l.astype(np.int64)]) ** 2).sum())
             assert abs(inertia(r0["C12"], lab) / inertia(Co, lo) - 1.0) < 1e-3
+
+
+def _kmeans_tiny_worker(rank, world, port, work):
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "tests"), os.path.join(root, "vector-indexer_amd")]
+    import oracle_lib as O
+    from vector_indexer_py import distributed as VD
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    X = np.load(os.path.join(work, "x.npy"))
+    n, d = X.shape
+    per = (n + world - 1) // world
+    b, e = min(n, rank * per), min(n, (rank + 1) * per)
+    Xl = torch.from_numpy(np.ascontiguousarray(X[b:e]) if e > b else np.zeros((1, d), np.float32))
+    pts = VD.ShardedPoints(Xl.data_ptr(), e - b, d, b, n, tensor=Xl)
+    Cb, Lb, it = VD.kmeans_parallel_sharded(_OracleEngine(O), VD.TorchComm("cpu"), pts, 2, 4, seed=3)
+    np.savez(os.path.join(work, f"tiny_{rank}.npz"), C=Cb.t[:2 * d].view(torch.float32).numpy().reshape(2, d).copy(),
+             L=Lb.t[:e - b].numpy().astype(np.uint32).copy(), n_local=np.array([e - b]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_lloyd_gloo_world_larger_than_n(tmp_path):
+    """world 3 over n = 2 points (one per rank: rank 2 owns nothing): the empty rank contributes zero sums and counts to the
+    all-reduce (run_kmeans_parallel's update, src/kmeans.rs:674-719, summed over ranks) instead of failing the loop"""
+    import torch.multiprocessing as mp
+    X = np.array([[0.0, 0.0, 1.0], [10.0, 10.0, 10.0]], dtype=np.float32)
+    work = str(tmp_path)
+    np.save(os.path.join(work, "x.npy"), X)
+    mp.spawn(_kmeans_tiny_worker, args=(3, _free_port(), work), nprocs=3, join=True)
+    r = [np.load(os.path.join(work, f"tiny_{i}.npz")) for i in range(3)]
+    assert [int(x["n_local"][0]) for x in r] == [1, 1, 0]
+    assert (r[0]["C"].view(np.uint32) == r[1]["C"].view(np.uint32)).all() and (r[0]["C"].view(np.uint32) == r[2]["C"].view(np.uint32)).all()
+    lab = np.concatenate([x["L"] for x in r])
+    assert sorted(lab.tolist()) == [0, 1]                       # two points, two clusters: each its own
+    assert np.allclose(np.sort(r[0]["C"], axis=0), np.sort(X, axis=0))
