@@ -343,6 +343,21 @@ def main():
         tot = sum(float(x.item()) for x in allsv)
         extras["scan_share_of_busiest_rank"] = {args.placement: round(max(float(x.item()) for x in allsv) / max(tot, 1.0), 4),
                                                 "ideal": round(1.0 / world, 4)}
+        # ... and under the OTHER partition rule, from one untimed step on a second handle (same files, same probe lists)
+        other = "shards" if args.placement == "stripes" else "stripes"
+        alt = vip.load(os.path.join(work, "index"), os.path.join(work, "shards"), d, device=local_rank, rank=rank, world_size=world,
+                       placement=1 if other == "shards" else 0)
+        alt.enable_timing(True)
+        p_eff = min(head, index.num_centroids)
+        po, pog, pa, oa = bufs_for(p_eff)
+        alt.search_probed_device(xq.data_ptr(), nq, k, p_eff, pa.data_ptr(), oa.data_ptr(), mine.data_ptr(), mine.data_ptr() + off_i,
+                                 mine.data_ptr() + off_t)
+        sv2 = torch.tensor([float(alt.last_stats()["scanned_vectors"])], dtype=torch.float64, device=device)
+        allsv2 = [torch.zeros_like(sv2) for _ in range(world)]
+        dist.all_gather(allsv2, sv2)
+        tot2 = sum(float(x.item()) for x in allsv2)
+        extras["scan_share_of_busiest_rank"][other] = round(max(float(x.item()) for x in allsv2) / max(tot2, 1.0), 4)
+        del alt
 
     if rank == 0 and world == 1 and not args.no_extras:
         # (a) the smallest nprobe of the sweep reaching recall@10 >= 0.95, timed the same way

@@ -381,7 +381,7 @@ struct CandArgs {
   uint32_t *cand, *cand_cnt;  // [(point * 2 + lane half) * kCandCap + slot], [point * 2 + lane half]
   float *cand_thr;            // [point]: the final threshold (minimum + margin) — entries listed under an earlier, looser one are dropped
   uint32_t pack16;            // k <= 65536: an entry is centroid | (its m0 rounded DOWN to bf16) << 16, so that the exact pass can drop them
-  uint32_t xmode;             // ablation knob (VI_CAND_XMODE, wrong results): 1 no candidate listing, 2 no epilogue at all
+  uint32_t xmode;             // ablation knob (VI_CAND_XMODE, wrong results): 1 no candidate listing, 2 no epilogue at all, 4 no tile copy / barrier
 };
 
 __global__ void centroid_hi_image_kernel(const float *C, uint32_t k, uint32_t d, uint32_t nc, uint4 *img) {
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
     const float *cur = lds + (s & 1) * kImgFloats;
     const uint32_t ct = tile_of(s);
     const bool record = s >= a.warm;
-    if (s + 1 < steps) dma_tile(lds + ((s + 1) & 1) * kImgFloats, tile_of(s + 1));
+    if (s + 1 < steps && !(a.xmode & 4u)) dma_tile(lds + ((s + 1) & 1) * kImgFloats, tile_of(s + 1));
     f32x16 acc[2][2];  // [centroid row tile][point tile]
     auto frag = [&](int c, int t) {
       return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4 *>(cur + ((c * 2 + h) * 64 + 32 * t + j) * 4));
@@ -526,8 +526,10 @@ __global__ void __launch_bounds__(256, 2) mfma_assign_cand_kernel(CandArgs a) {
       b1[p] = fminf(b1[p], smin);
       thr[p] = b1[p] + margin[p];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // next tile visible; this one free to be overwritten
+    if (!(a.xmode & 4u)) {  // (ablation 4: the same tile again and again, no copy, no barrier)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // next tile visible; this one free to be overwritten
+    }
   };
   dma_tile(lds, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
