@@ -472,6 +472,31 @@ def test_striped_ranks_beyond_the_wave_select_limits(tmp_path):
         hip.close()
 
 
+def test_byte_lists_with_integer_and_other_queries(tmp_path):
+    """8-bit lists (every stored value an integer in 0..255): a query that is integer-valued in 0..255 too takes the
+    byte-dot-product form of the exact distance (every partial sum of src/utils.rs:28-30 is then an integer below 2^24:
+    the chain never rounds), any other query the f32 chain — in ONE batch, boundary values included, D = 128 and a
+    D that is not a multiple of 16"""
+    rng = np.random.default_rng(77)
+    for d in (128, 20):
+        X = rng.integers(0, 256, size=(6000, d)).astype(np.float32)
+        X[:50] = 255.0                                  # the largest possible terms: 255^2 per dimension
+        X[50:100] = 0.0
+        sub = tmp_path / f"d{d}"
+        sub.mkdir()
+        orc, gpu = oracle_and_gpu(sub, X, nlist=40)
+        Q = rng.integers(0, 256, size=(240, d)).astype(np.float32)
+        Q[0] = 0.0
+        Q[1] = 255.0
+        Q[2:40] += 0.5                                  # not integers
+        Q[40:60, 3] = 256.0                             # an integer just out of range
+        Q[60:80, 5] = -1.0
+        Q[80:100] = X[100:120]                          # exact hits (distance 0)
+        Q[100:120] *= np.float32(1.0000001)             # (rounds to neighbours of integers: most stay non-integers)
+        for k, n_probe in [(10, 8), (64, 40), (100, 16)]:
+            check_parity(orc, gpu, Q, k, n_probe)
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_shard_placement_ranks_merge_to_the_single_gpu_result(world, tmp_path):
     """north_star's partition rule (vi_config.placement = 1): whole shard files — the reference's super-centroid grouping,
