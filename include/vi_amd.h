@@ -318,7 +318,9 @@ typedef struct vi_search_stats {
   uint64_t filter_accepted;    /* VI_FILTER_STATS=1: block records consulted */
   uint64_t rank_mode;          /* list scan of the last search: 0 exact-order VALU engine, 1 f32 MFMA,
                                   2 bf16 x 3 MFMA, 3 bf16 MFMA on hi planes only (bf16-exact stored values),
-                                  4 bf16 MFMA on the hi planes of real-valued lists (wider margin, more exact re-evaluations) */
+                                  4 bf16 MFMA on the hi planes of real-valued lists (wider margin, more exact re-evaluations),
+                                  5 / 6 = 2 / 4 with the images taken about the mean of the stored vectors (real-valued
+                                  lists far from the origin: the margins scale with the spread, not the offset) */
   uint64_t group_queries;      /* MFMA path: queries per rank work item (128, or 32 when lists are probed by few) */
 } vi_search_stats;
 /* phases of the most recent build on this handle (wall-clock ms): the points are uploaded once; k-means, the grouping of

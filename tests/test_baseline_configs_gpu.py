@@ -309,7 +309,7 @@ def test_c5_per_rank_slice_n12_5m_d96_nlist65536(tmp_path_factory):
             assert rc == O.ORC_OK
             Dg, Ig = gpu.search_sync(xq[:nq], k, n_probe)
             st = gpu.last_stats()
-            assert st["rank_mode"] in (2, 4), st                  # real-valued lists on the matrix cores (bf16 x 3, or hi planes + margin), not a fallback
+            assert st["rank_mode"] in (2, 4, 5, 6), st                  # real-valued lists on the matrix cores (bf16 x 3, or hi planes + margin), not a fallback
             assert_same(Dg, Ig, Do, Io, f"C5 slice nprobe {n_probe}")
     finally:
         import shutil

@@ -595,3 +595,39 @@ def test_streaming_rank_kernel_parity(n, d, nq, k, P, nlist, variant, tmp_path, 
         st = gpu.last_stats()
         if os.environ.get("VI_FILTER_HI_ONLY") != "0":
             assert st["rank_mode"] == 3   # hi planes only
+
+
+@pytest.mark.parametrize("d,n,nlist", [(64, 20000, 0), (128, 12000, 60), (20, 9000, 0),
+                                       (32, 30000, 1024)])   # >= 1024 lists and >= 256 queries: the coarse step runs on the centred table too
+@pytest.mark.parametrize("approx", ["auto", "0", "1", "2"])
+@pytest.mark.parametrize("centre", ["auto", "0", "1"])
+def test_real_valued_lists_far_from_the_origin(d, n, nlist, approx, centre, tmp_path, monkeypatch):
+    """Real-valued lists whose common offset dwarfs their spread: the ranking images are taken about the mean of the
+    stored vectors (rank_mode 5 / 6) and, spread permitting, from the hi planes alone; VI_CENTER / VI_RANK_APPROX force
+    every combination.  None of it may show in a result: ids and distance bits of the oracle, for queries near the
+    data, far from it, on stored vectors, and at the origin."""
+    if os.environ.get("VI_FILTER") == "0" or os.environ.get("VI_FILTER_BF16") == "0":
+        pytest.skip("centred images belong to the bf16 MFMA engine")
+    if centre != "auto":
+        monkeypatch.setenv("VI_CENTER", centre)
+    if approx != "auto":
+        monkeypatch.setenv("VI_RANK_APPROX", approx)
+    rng = np.random.default_rng(d * 7 + n)
+    centers = (100.0 + 6.0 * rng.standard_normal((24, d))).astype(np.float32)
+    X = (centers[rng.integers(0, 24, n)] + rng.standard_normal((n, d)).astype(np.float32) * 1.5).astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    near = (centers[rng.integers(0, 24, 300)] + rng.standard_normal((300, d)).astype(np.float32) * 1.5).astype(np.float32)
+    far = (rng.standard_normal((40, d)) * 300.0).astype(np.float32)
+    Q = np.ascontiguousarray(np.concatenate([near, far, X[100:140], np.zeros((2, d), np.float32)]))
+    for k, n_probe in [(10, 8), (1, 1), (64, 20), (100, 5)]:
+        check_parity(orc, gpu, Q, k, n_probe)
+        mode = gpu.last_stats()["rank_mode"]
+        if centre == "0":
+            assert mode in (2, 4), mode
+        else:
+            assert mode in (5, 6), mode   # (auto: |mu|^2 = 10^4 d against a spread of ~40 d)
+        if approx == "0" or os.environ.get("VI_FILTER_HI_ONLY") == "0":
+            assert mode in (2, 5), mode
+        elif approx in ("1", "2"):
+            assert mode in (4, 6), mode
+    check_parity(orc, gpu, Q[:7], 10, 8)

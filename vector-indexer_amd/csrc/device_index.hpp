@@ -105,6 +105,13 @@ struct DeviceIndex {
   // sampled means over the stored vectors: ||v - centroid of its list||^2 and ||v||^2 (what the ranking arithmetic of
   // real-valued lists is chosen by: filter_search.hip, rank_approx_mode)
   float mean_spread = 0.0f, mean_norm2 = 0.0f;
+  float rho2_max = 0.0f;  // max |x - hi(x)|^2 over the stored vectors (x = v - mu when centred): the hi-plane ranking's margin
+  // Real-valued lists far from the origin (SIFT-like values with noise, embeddings with a common offset): the bf16 images
+  // are taken about the mean mu of the stored vectors — ||q - v|| does not change, the norms the rank margins scale with
+  // shrink to the spread of the data.  Only the ranking sees mu; the exact evaluation reads the stored f32 values.
+  bool centered = false;
+  DevBuf<float> centre;  // mu: dq * 4 floats (zero beyond dim)
+  float mean_norm2_c = 0.0f, xmax2_c = 0.0f, cent_xmax2_c = 0.0f;  // ... and the norms about mu
   float xmax2 = 0.0f;                 // max squared norm of a stored vector (MFMA filter margin)
   DevBuf<float> cent_xnorm;           // same for the coarse table
   DevBuf<float> cent_rows;            // the coarse table row-major (coarse select: single-row exact re-evaluation)

@@ -69,15 +69,19 @@ constexpr uint32_t kMaxFilterDim = 1536;  // the MFMA engine's dimension limit (
 constexpr int kGroupQ = 128;       // queries per work item: 4 waves x one MFMA column tile of 32
 constexpr uint32_t kPosBits = 26;  // candidate key = (probe rank << 26) | position in list
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1u;
+constexpr double kApproxRatio = 0.04;  // rank_approx_mode: margin unit / list spread up to which the hi planes alone rank
 constexpr float kBig = 3.0e38f;            // norm of pad slots inside the kernel (finite: low bits are reused)
 
-__global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, float *xnorm, uint32_t *xmax_bits) {
+// mu (or null): the centre the ranking images are taken about (mean_kernel) — the norm of fl(v - mu) then
+__global__ void slot_norms_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, float *xnorm, uint32_t *xmax_bits,
+                                  const float4 *mu = nullptr) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
   double acc = 0.0;  // (pad slots hold zeros: they are marked by pad_norms_kernel from the list layout afterwards)
   const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
   for (uint32_t qd = 0; qd < dq; ++qd) {
-    const float4 v = p[(size_t)qd * kWave];
+    float4 v = p[(size_t)qd * kWave];
+    if (mu) { const float4 m = mu[qd]; v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
     acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
   }
   float out = (float)acc;
@@ -93,6 +97,67 @@ __global__ void pad_norms_kernel(const uint32_t *first_block, const uint32_t *li
   if (l >= nlists) return;
   const uint32_t len = list_len[l], p = len + j;
   if (p < ((len + 63u) & ~63u)) xnorm[(size_t)first_block[l] * kWave + p] = kBig;  // (finite: the kernel reuses the low mantissa bits)
+}
+
+// component sums of all stored vectors (pad slots hold zeros): WG (quad, g) walks blocks g, g + G, ..., a lane per vector;
+// one atomic per component and work-group.  sums: dq * 4 doubles.
+__global__ void mean_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, double *sums) {
+  const uint32_t qd = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (uint64_t b = (uint64_t)blockIdx.y * 4 + wave; b < nblocks; b += (uint64_t)gridDim.y * 4) {
+    const float4 v = blocks[(b * dq + qd) * 64 + lane];
+    a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); a3 += __shfl_xor(a3, o);
+  }
+  if (lane == 0) {
+    atomicAdd(sums + 4 * qd + 0, a0); atomicAdd(sums + 4 * qd + 1, a1);
+    atomicAdd(sums + 4 * qd + 2, a2); atomicAdd(sums + 4 * qd + 3, a3);
+  }
+}
+__global__ void sum_f32_kernel(const float *x, uint64_t n, double *out) {  // finite entries only (pad slots hold kBig)
+  double a = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v < 1.0e37f) a += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63u) == 0u) atomicAdd(out, a);
+}
+__global__ void max_finite_kernel(const float *x, uint64_t n, uint32_t *bits) {  // non-negative entries; pad slots (kBig) skipped
+  float m = 0.0f;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v < 1.0e37f) m = fmaxf(m, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63u) == 0u) atomicMax(bits, __float_as_uint(m));
+}
+// max over the stored vectors of |x - hi(x)|^2, x = v - mu and hi = its bf16 image: what ranking from the hi planes alone
+// leaves out of q.v is at most |q| times the root of this (pad slots — norm kBig in `norms` — do not count)
+__global__ void trunc_residual_kernel(const float4 *blocks, uint32_t dq, uint64_t nslots, const float *norms, const float4 *mu,
+                                      uint32_t *max_bits) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float out = 0.0f;
+  if (s < nslots && norms[s] < 1.0e37f) {
+    double acc = 0.0;
+    const float4 *p = blocks + (s / kWave) * dq * kWave + (s % kWave);
+    for (uint32_t qd = 0; qd < dq; ++qd) {
+      float4 v = p[(size_t)qd * kWave];
+      if (mu) { const float4 m = mu[qd]; v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+      const float r0 = v.x - __uint_as_float(bf16_rn(v.x) << 16), r1 = v.y - __uint_as_float(bf16_rn(v.y) << 16);
+      const float r2 = v.z - __uint_as_float(bf16_rn(v.z) << 16), r3 = v.w - __uint_as_float(bf16_rn(v.w) << 16);
+      acc += (double)r0 * r0 + (double)r1 * r1 + (double)r2 * r2 + (double)r3 * r3;
+    }
+    out = (float)(acc * 1.000001);
+  }
+  for (int o = 32; o > 0; o >>= 1) out = fmaxf(out, __shfl_xor(out, o));
+  if ((threadIdx.x & 63u) == 0u && out > 0.0f) atomicMax(max_bits, __float_as_uint(out));
+}
+__global__ void mean_finish_kernel(const double *sums, uint32_t dim, uint32_t dim_pad, double n, float *mu) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < dim_pad) mu[e] = e < dim ? (float)(sums[e] / n) : 0.0f;
 }
 
 // sampled spread of the lists: sums of ||v - c(list)||^2 and ||v||^2 over the first blocks of every list (one wave per list)
@@ -135,7 +200,7 @@ __host__ __device__ inline uint32_t image_column(uint32_t v) {
   return 32u * t + (e & 3u) + 8u * (e >> 2) + 4u * h;
 }
 
-__global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, uint4 *out) {
+__global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nblocks, uint4 *out, const float4 *mu = nullptr) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block, chunk, half, vector)
   const uint32_t nc = dq / 4;
   if (t >= nblocks * nc * 2 * 64) return;
@@ -145,7 +210,13 @@ __global__ void split_bf16_kernel(const float4 *blocks, uint32_t dq, uint64_t nb
   const uint64_t b = bc / nc;
   const float4 *src = blocks + (b * dq + 4 * c + 2 * h) * 64 + v;
   uint4 hi, lo;
-  split8(src[0], src[64], 1.0f, hi, lo);
+  float4 v0 = src[0], v1 = src[64];
+  if (mu) {  // the image of fl(v - mu)
+    const float4 m0 = mu[4 * c + 2 * h], m1 = mu[4 * c + 2 * h + 1];
+    v0.x -= m0.x; v0.y -= m0.y; v0.z -= m0.z; v0.w -= m0.w;
+    v1.x -= m1.x; v1.y -= m1.y; v1.z -= m1.z; v1.w -= m1.w;
+  }
+  split8(v0, v1, 1.0f, hi, lo);
   uint4 *dst = out + ((b * nc + c) * 4) * 64;
   const uint32_t col = image_column(v);
   dst[(0 * 2 + h) * 64 + col] = hi;
@@ -415,7 +486,7 @@ __device__ __forceinline__ void tile_dma_rank(float *tile, const float4 *src, co
 }
 
 __global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo,
-                                     uint32_t *zero, uint32_t zero_words);
+                                     uint32_t *zero, uint32_t zero_words, const float *mu);
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(uint32_t n) {
@@ -751,8 +822,9 @@ struct WideArgs {
 // (a batch of bf16-exact queries is ranked from its hi planes alone: they are whole cache lines of their own)
 // *any_lo is raised when some query has a non-zero lo plane (a batch of bf16-exact queries is ranked without them)
 // (`zero`: a buffer the next kernels count into — the coarse step's per-list histogram — cleared here instead of by a memset launch)
+// mu (or null): the centre of the ranking images (DeviceIndex::centre) — the image is then that of -2 fl(q - mu)
 __global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, uint32_t nc, uint4 *out, unsigned long long *any_lo,
-                                     uint32_t *zero, uint32_t zero_words) {
+                                     uint32_t *zero, uint32_t zero_words, const float *mu) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (query, chunk, half)
   for (uint64_t i = t; i < zero_words; i += (uint64_t)gridDim.x * blockDim.x) zero[i] = 0u;
   if (t >= (uint64_t)nq * nc * 2) return;
@@ -765,6 +837,10 @@ __global__ void split_queries_kernel(const float *Q, uint32_t nq, uint32_t dim, 
   float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
   if (e < dim) v0 = *reinterpret_cast<const float4 *>(row + e);        // dim % 4 == 0
   if (e + 4 < dim) v1 = *reinterpret_cast<const float4 *>(row + e + 4);
+  if (mu) {
+    if (e < dim) { const float4 m = *reinterpret_cast<const float4 *>(mu + e); v0.x -= m.x; v0.y -= m.y; v0.z -= m.z; v0.w -= m.w; }
+    if (e + 4 < dim) { const float4 m = *reinterpret_cast<const float4 *>(mu + e + 4); v1.x -= m.x; v1.y -= m.y; v1.z -= m.z; v1.w -= m.w; }
+  }
   uint4 hi, lo;
   split8(v0, v1, -2.0f, hi, lo);
   out[q * 4 * nc + 2 * c + h] = hi;
@@ -922,6 +998,9 @@ struct SelectCommon {
   const uint4 *u8_nat;      // 8-bit descriptors: one byte per dimension (u8_natural_kernel), else null
   uint32_t wave_order;      // pair records in the streaming kernel's wave order (scan.hpp: seg_records), else pair order
   uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
+  const float *mu;          // centre of the ranking images (rank values are those of q - mu against v - mu), or null
+  uint32_t trunc;           // real-valued lists ranked from their hi planes: 1 queries hi + lo, 2 queries' hi plane only; 0 otherwise
+  float rho_max, vmax;      // ... max |v - hi(v)| and max |v| over the lists (rounded up)
 };
 
 // the query's probes, one per lane r < P
@@ -1160,17 +1239,20 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  float qn = 0.0f;
+  float qn = 0.0f, qres = 0.0f;
   bool q_bytes = c.u8_nat != nullptr && qbytes != nullptr && c.dim <= 256u;  // -> the query is integer-valued in 0..255
   for (uint32_t e = lane; e < c.dim; e += kWave) {  // the query row: into LDS for the exact evaluations, and its norm
     const float v = c.Q[(size_t)q * c.dim + e];
     qlds[e] = v;
-    qn += v * v;
+    const float vc = c.mu ? v - c.mu[e] : v;  // the margins live where the rank values do
+    qn += vc * vc;
+    const float im = -2.0f * vc, ir = im - __uint_as_float(bf16_rn(im) << 16);  // what the hi plane of the query image leaves out
+    qres += ir * ir;
     q_bytes = q_bytes && v >= 0.0f && v <= 255.0f && v == floorf(v);
   }
   q_bytes = __ballot(!q_bytes) == 0ull;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
+  for (int o = 32; o > 0; o >>= 1) { qn += __shfl_xor(qn, o); qres += __shfl_xor(qres, o); }
   uint32_t qn_int = 0u;
   if (q_bytes) {  // the query as bytes, zero padded to whole 16-byte pieces (exact_pair_u8_int), and |q|^2 as an integer
     const uint32_t nw = ((c.dim + 15u) >> 4) * 4u;
@@ -1188,7 +1270,10 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qn_int += (uint32_t)__shfl_xor((int)qn_int, o);
   }
-  const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
+  // hi planes of real-valued lists: the image (-2q) . v is ranked as (-2q) . hi(v) [trunc 1] or hi(-2q) . hi(v) [trunc 2];
+  // |(-2q) . (v - hi v)| <= 2 |q| rho_max, and |(-2q - hi(-2q)) . v| <= |query residual| max|v|  (|hi(-2q)| <= 2 |q| (1 + 2^-8))
+  if (c.trunc) E += 1.02f * (2.0f * sqrtf(qn) * c.rho_max * (1.0f + 0.00391f) + (c.trunc == 2u ? sqrtf(qres) * c.vmax : 0.0f));
   // a query so large that the rank arithmetic may have overflowed (inf - inf = NaN, and NaN fails every guard
   // below): trust no rank value, re-evaluate everything the query probes
   const bool distrust = !(qn < 1.0e30f);
@@ -1620,7 +1705,8 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   for (uint32_t e = lane; e < c.dim; e += kWave) {
     const float v = c.Q[(size_t)q * c.dim + e];
     qlds[e] = v;
-    qn += v * v;
+    const float vc = c.mu ? v - c.mu[e] : v;
+    qn += vc * vc;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
@@ -1814,32 +1900,33 @@ bool hi_only_ok() {
 }
 
 // Real-valued lists (not bf16-exact) ranked from their hi planes alone instead of hi + lo (bf16 x 3): a third (queries'
-// hi + lo planes: mode 1) or a sixth (queries' hi plane only: mode 2) of the matrix work, paid for with a wider margin —
-// bf16 keeps 8 significant bits, |v - hi(v)| <= 2^-8 |v|, so 2 |q.v - q.hi(v)| <= 2^-7 |q||v| <= 2^-8 (|q|^2 + |v|^2), twice
-// that when the queries are truncated too — which the select turns into more sub-blocks re-evaluated exactly; no result
-// depends on a rank value (file header).  Chosen per index from its sampled spread; VI_RANK_APPROX=0 / 1 / 2 forces
-// bf16 x 3 / queries hi + lo / queries' hi plane only.
-double rank_approx_e(int mode);
+// hi + lo planes: mode 1) or a sixth (queries' hi plane only: mode 2) of the matrix work, paid for with a wider margin
+// (select_body: 2 |q| max|v - hi(v)|, plus |query residual| max|v| in mode 2 — the residual norms are measured, not
+// bounded by 2^-8 |v|: rounding to nearest leaves about a third of that), which the select turns into more sub-blocks
+// re-evaluated exactly; no result depends on a rank value (file header).  Chosen per index from its sampled spread;
+// VI_RANK_APPROX=0 / 1 / 2 forces bf16 x 3 / queries hi + lo / queries' hi plane only.
 int rank_approx_mode(const DeviceIndex &ix) {
-  auto unit = [&](int mode) { return rank_approx_e(mode) * ((double)ix.mean_norm2 + 2.0 * (double)ix.xmax2); };
   if (const char *e = getenv("VI_RANK_APPROX")) {
     const int v = atoi(e);
     return v < 0 || v > 2 ? 1 : v;
   }
+  // a typical query is as long as a typical stored vector, and its image's residual about twice that of a stored vector's
+  const double qlen = std::sqrt((double)(ix.centered ? ix.mean_norm2_c : ix.mean_norm2));
+  const double vmax = std::sqrt((double)(ix.centered ? ix.xmax2_c : ix.xmax2)), rho = std::sqrt((double)ix.rho2_max);
+  const double unit1 = 2.0 * qlen * rho, unit2 = unit1 + 2.0 * rho * vmax;
+  if (getenv("VI_DEBUG_APPROX"))
+    fprintf(stderr, "[vi] approx: centred %d qlen %.4g vmax %.4g rho %.4g spread %.4g unit1/spread %.4g unit2/spread %.4g\n", (int)ix.centered,
+            qlen, vmax, rho, (double)ix.mean_spread, unit1 / (double)ix.mean_spread, unit2 / (double)ix.mean_spread);
   // The margin grows by `unit`; what it admits grows with unit / (distance of a vector to its neighbours), for which the
-  // spread of the lists stands in.  Measured: N(0,1) D=96 (ratio 0.034 in mode 2): 4.1 -> 3.0 ms per 10 000 queries;
-  // uncentred SIFT-like values with noise (ratio 0.2 in mode 1): 0.89 -> 1.40 ms — the select drowns in re-evaluations.
+  // spread of the lists stands in.
   if (!(ix.mean_spread > 0.0f)) return 0;
-  if (unit(2) <= 0.04 * ix.mean_spread) return 2;
-  if (unit(1) <= 0.04 * ix.mean_spread) return 1;
+  if (unit2 <= kApproxRatio * ix.mean_spread) return 2;
+  if (unit1 <= kApproxRatio * ix.mean_spread) return 1;
   return 0;
-}
-double rank_approx_e(int mode) {
-  return mode == 2 ? 1.01 * std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) : mode == 1 ? 1.01 * std::ldexp(1.0, -8) : 0.0;
 }
 
 SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 *blocks, float xmax2, uint32_t gq, bool wave_order = false,
-                           double e_trunc = 0.0) {
+                           int trunc = 0) {
   const double u = 1.01 * std::ldexp(1.0, -24);
   SelectCommon c{};
   c.Q = Qd; c.dim = ix.dim; c.dq = ix.dq; c.blocks = blocks;
@@ -1853,9 +1940,16 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   //              |q||v| <= 2^-15 (|q|^2 + |v|^2) — round 2 budgeted 3 * 2^-18 here, 2.7 times too little), and
   //              (3D+2) * 2u' for the f32 accumulation of 3D exact bf16 products (2u': also covers an accumulator that truncates)
   const double acc = rank_bf16() ? (3.0 * ix.dim + 2.0) * 2.0 * u + 1.01 * std::ldexp(1.0, -15) : (ix.dim + 2.0) * u;
-  //   e_trunc  : real-valued lists ranked from their bf16 hi planes alone (rank_approx_mode below)
-  c.e_scale = (float)(acc + e_trunc);
+  //   (real-valued lists ranked from their bf16 hi planes alone: SelectCommon::trunc, added per query in select_body)
+  // centred images (DeviceIndex::centered): v - mu and q - mu are rounded before they are split — the ranked pair sits
+  // within 2^-24 (|q'| + |v'|) of the true one, its distance within 4 * 2^-24 (|q'|^2 + |v'|^2) of the true distance
+  const bool centred = ix.centered && rank_bf16();
+  c.e_scale = (float)(acc + (centred ? 6.0 * u : 0.0));
+  c.trunc = (uint32_t)trunc;
+  c.rho_max = (float)(std::sqrt((double)ix.rho2_max) * 1.0001);
+  c.vmax = (float)(std::sqrt((double)xmax2) * 1.0001);
   c.xmax2 = xmax2;
+  c.mu = centred ? ix.centre.p : nullptr;
   c.gq = gq;
   c.image_order = rank_bf16() ? 1u : 0u;
   c.wave_order = wave_order ? 1u : 0u;
@@ -1960,6 +2054,93 @@ vi_status compute_slot_norms(DeviceIndex *ix) {
     VI_HIP(hipStreamSynchronize(ix->stream));
     ix->lists_lo_zero = np_l > 0 && h_any[0] == 0;
     ix->cent_lo_zero = np_c > 0 && h_any[1] == 0;
+    ix->centered = false;
+    const char *ce = getenv("VI_CENTER");
+    if (!ix->lists_lo_zero && ix->dim <= kNarrowDim && ix->nlists && ix->nvec_resident && !(ce && *ce == '0')) {
+      // real-valued lists: images about the mean of the stored vectors when that at least halves the norms the margins
+      // scale with (VI_CENTER=1: always, =0: never)
+      DevBuf<double> sums;
+      DevBuf<float> cn, ccn;
+      DevBuf<double> nsum;
+      VI_TRY(sums.reserve((uint64_t)ix->dq * 4));
+      VI_TRY(ix->centre.reserve((uint64_t)ix->dq * 4));
+      VI_TRY(cn.reserve(nslots));
+      VI_TRY(ccn.reserve(cslots));
+      VI_HIP(hipMemsetAsync(sums.p, 0, (uint64_t)ix->dq * 4 * sizeof(double), ix->stream));
+      hipLaunchKernelGGL(mean_kernel, dim3(ix->dq, 64), dim3(256), 0, ix->stream, (const float4 *)ix->lists.blocks.p, ix->dq,
+                         ix->lists.nblocks, sums.p);
+      hipLaunchKernelGGL(mean_finish_kernel, dim3((ix->dq * 4 + 255) / 256), dim3(256), 0, ix->stream, sums.p, ix->dim, ix->dq * 4,
+                         (double)ix->nvec_resident, ix->centre.p);
+      uint32_t mxb[2] = {0u, 0u};
+      DevBuf<uint32_t> mx2;
+      VI_TRY(mx2.reserve(2));
+      VI_HIP(hipMemsetAsync(mx2.p, 0, 8, ix->stream));
+      hipLaunchKernelGGL(slot_norms_kernel, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->lists.blocks.p, ix->dq, nslots, cn.p, mx2.p, (const float4 *)ix->centre.p);
+      hipLaunchKernelGGL(slot_norms_kernel, dim3((uint32_t)((cslots + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->centroids.blocks.p, ix->dq, (uint64_t)ix->nlists, ccn.p, mx2.p + 1, (const float4 *)ix->centre.p);
+      hipLaunchKernelGGL(pad_norms_kernel, dim3((uint32_t)((ix->nlists * 64 + 255) / 256)), dim3(256), 0, ix->stream,
+                         ix->list_first_block.p, ix->list_len.p, (uint32_t)ix->nlists, cn.p);
+      VI_HIP(hipMemsetAsync(mx2.p, 0, 8, ix->stream));  // (the pad slots' zero vectors entered the kernel's own maximum)
+      hipLaunchKernelGGL(max_finite_kernel, dim3(256), dim3(256), 0, ix->stream, cn.p, nslots, mx2.p);
+      hipLaunchKernelGGL(max_finite_kernel, dim3(64), dim3(256), 0, ix->stream, ccn.p, (uint64_t)ix->nlists, mx2.p + 1);
+      VI_HIP(hipGetLastError());
+      VI_HIP(hipMemcpyAsync(mxb, mx2.p, 8, hipMemcpyDeviceToHost, ix->stream));
+      std::vector<double> hs((size_t)ix->dq * 4);
+      VI_HIP(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
+      VI_HIP(hipStreamSynchronize(ix->stream));
+      float xc, cc;
+      std::memcpy(&xc, &mxb[0], 4);
+      std::memcpy(&cc, &mxb[1], 4);
+      double mu2 = 0.0;  // |mu|^2; the mean of |v - mu|^2 is the mean of |v|^2 less this
+      for (uint32_t e = 0; e < ix->dim; ++e) { const double m = hs[e] / (double)ix->nvec_resident; mu2 += m * m; }
+      double mean_raw = 0.0;
+      {  // the mean squared norm of ALL stored vectors (list_spread_kernel below only samples)
+        DevBuf<double> acc;
+        VI_TRY(acc.reserve(1));
+        VI_HIP(hipMemsetAsync(acc.p, 0, sizeof(double), ix->stream));
+        hipLaunchKernelGGL(sum_f32_kernel, dim3(256), dim3(256), 0, ix->stream, ix->xnorm.p, nslots, acc.p);
+        VI_HIP(hipGetLastError());
+        VI_HIP(hipMemcpyAsync(&mean_raw, acc.p, sizeof(double), hipMemcpyDeviceToHost, ix->stream));
+        VI_HIP(hipStreamSynchronize(ix->stream));
+        mean_raw /= (double)ix->nvec_resident;
+      }
+      const double mean_c = std::max(0.0, mean_raw - mu2);
+      const bool gain = mean_c + 2.0 * (double)xc < 0.5 * (mean_raw + 2.0 * (double)ix->xmax2);
+      if ((ce && *ce == '1') || gain) {
+        ix->centered = true;
+        ix->mean_norm2_c = (float)mean_c;
+        ix->xmax2_c = xc;
+        ix->cent_xmax2_c = cc;
+        const uint64_t npad = cslots - ix->nlists;
+        if (npad) {
+          std::vector<float> inf(npad, kBig);
+          VI_HIP(hipMemcpyAsync(ccn.p + ix->nlists, inf.data(), npad * 4, hipMemcpyHostToDevice, ix->stream));
+          VI_HIP(hipStreamSynchronize(ix->stream));  // (inf lives on this frame)
+        }
+        hipLaunchKernelGGL(image_norms_kernel, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, ix->stream, cn.p, nslots,
+                           ix->xnorm_img.p);
+        hipLaunchKernelGGL(image_norms_kernel, dim3((uint32_t)((cslots + 255) / 256)), dim3(256), 0, ix->stream, ccn.p, cslots,
+                           ix->cent_xnorm_img.p);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nt_l + 255) / 256)), dim3(256), 0, ix->stream,
+                           (const float4 *)ix->lists.blocks.p, ix->dq, ix->lists.nblocks, (uint4 *)ix->lists_bf16.p, (const float4 *)ix->centre.p);
+        hipLaunchKernelGGL(split_bf16_kernel, dim3((uint32_t)((nt_c + 255) / 256)), dim3(256), 0, ix->stream,
+                           (const float4 *)ix->centroids.blocks.p, ix->dq, ix->centroids.nblocks, (uint4 *)ix->cent_bf16.p, (const float4 *)ix->centre.p);
+        VI_HIP(hipGetLastError());
+        VI_HIP(hipStreamSynchronize(ix->stream));
+        ix->cent_lo_zero = false;
+      }
+    }
+    ix->rho2_max = 0.0f;
+    if (!ix->lists_lo_zero && ix->dim <= kNarrowDim && nslots) {  // real-valued lists: what their hi planes leave out (rank_approx_mode)
+      VI_HIP(hipMemsetAsync(mx.p, 0, 4, ix->stream));
+      hipLaunchKernelGGL(trunc_residual_kernel, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, ix->stream,
+                         (const float4 *)ix->lists.blocks.p, ix->dq, nslots, ix->xnorm.p, ix->centered ? (const float4 *)ix->centre.p : nullptr, mx.p);
+      VI_HIP(hipGetLastError());
+      VI_HIP(hipMemcpyAsync(&bits, mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
+      VI_HIP(hipStreamSynchronize(ix->stream));
+      std::memcpy(&ix->rho2_max, &bits, 4);
+    }
     if (ix->nlists && ix->dim <= kNarrowDim) {  // single-row exact re-evaluation of the coarse select
       const uint32_t nquad = ix->dim / 4;
       VI_TRY(ix->cent_rows.reserve((uint64_t)ix->nlists * ix->dim));
@@ -2063,7 +2244,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     VI_TRY(launch_filter(a, dq, ngroups * nseg, rank_bf16() ? (ix.cent_lo_zero && hi_only_ok() ? 2 : 1) : 0, kGroupQ, st));
   }
   {
-    CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, ix.cent_xmax2, kGroupQ), (uint32_t)nq, P,
+    CoarseSelectArgs a{select_common(ix, Qd, (const float4 *)ix.centroids.blocks.p, rank_bf16() && ix.centered ? ix.cent_xmax2_c : ix.cent_xmax2, kGroupQ), (uint32_t)nq, P,
                        (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
                        ws.cnt.p, qmajor ? 1u : 0u, nullptr, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_COARSE_ROWS"); if (ix.cent_rows.p && !(e && *e == '0')) a.cent_rows = (const float4 *)ix.cent_rows.p; }
@@ -2111,7 +2292,8 @@ static vi_status build_query_image(const DeviceIndex &ix, const float *Qd, uint6
   }
   const uint64_t nt = (uint64_t)nq * nc * 2;
   hipLaunchKernelGGL(split_queries_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, st, Qd, (uint32_t)nq, ix.dim, nc,
-                     (uint4 *)ws.qimg.p, (unsigned long long *)(ws.stats.p + 13), zero, (uint32_t)zero_words);
+                     (uint4 *)ws.qimg.p, (unsigned long long *)(ws.stats.p + 13), zero, (uint32_t)zero_words,
+                     ix.centered ? (const float *)ix.centre.p : nullptr);
   VI_HIP(hipGetLastError());
   return VI_OK;
 }
@@ -2261,6 +2443,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     }
     const int rank_mode = rank_bf16() ? (hi_lists ? 2 : 1) : 0;
     stt.rank_mode = approx ? 4u : (uint64_t)rank_mode + 1;
+    if (rank_bf16() && ix.centered && (stt.rank_mode == 2 || stt.rank_mode == 4)) stt.rank_mode = stt.rank_mode == 2 ? 5 : 6;  // the same about the mean
     stt.group_queries = gq;
     if (stream) {
       // queries in LDS, vectors through registers, no barrier in the block loop, persistent workgroups (rank_stream.hip)
@@ -2334,7 +2517,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
   // ---- 4. select ----
   {
-    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, ix.xmax2, gq, stream, rank_approx_e(approx)), (uint32_t)nq, P, (uint32_t)k, segb0,
+    SelectArgs a{select_common(ix, Qd, (const float4 *)ix.lists.blocks.p, rank_bf16() && ix.centered ? ix.xmax2_c : ix.xmax2, gq, stream, approx), (uint32_t)nq, P, (uint32_t)k, segb0,
                  ws.qoff.p, ws.qtot.p, ws.pair_rel.p, ws.pair_pos.p, ws.tile_start.p, ws.probes.p, ws.gorder.p, ix.list_first_block.p, ix.list_len.p,
                  ix.ext_ids.p, Dd, Id, Td, slots, counts};
     { const char *e = getenv("VI_FILTER_STATS"); if (e && *e == '2') a.c.dbg = nullptr; }
