@@ -1,0 +1,17 @@
+import os, sys
+os.environ["VI_FILTER_STATS"] = sys.argv[1]
+ROOT = "/root/repo"
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-indexer_amd")]
+import torch, bench, tempfile, shutil
+import vector_indexer_py as vip
+dev = torch.device("cuda", 0)
+xb, xq = bench.make_dataset(1_000_000, 128, 10000, 42, dev)
+work = "/tmp/vi_stats_probe"
+shutil.rmtree(work, ignore_errors=True)
+idx = vip.build(xb.cpu().numpy(), work, nlist=4096, now_secs=1_700_000_000)
+idx.enable_timing(True)
+D = torch.empty((10000, 10), dtype=torch.float32, device=dev); I = torch.empty((10000, 10), dtype=torch.int64, device=dev)
+for r in range(3):
+    idx.search_device(xq.data_ptr(), 10000, 10, 32, D.data_ptr(), I.data_ptr(), 0)
+st = idx.last_stats()
+print("STATS", sys.argv[1], {k: st[k] for k in ("filter_rechecked", "filter_accepted", "ms_coarse", "ms_merge")})

@@ -1013,27 +1013,58 @@ struct ProbeRegs {
   uint32_t g;         // candidate-order rank (shard visiting order)
 };
 
+// Loads with the address space spelled out.  The exact-evaluation pieces below are real functions (noinline), so their
+// pointer arguments are generic and every access through them compiles to flat_load: the query row in LDS then goes through
+// the vector-memory address pipe — the unit the gathers of stored vectors saturate — and every wait covers both counters.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+// a - b on two floats in one instruction (v_pk_add_f32 with the second operand negated: every component rounds as
+// v_sub_f32 does; the compiler turns a vector subtraction back into two scalar ones)
+__device__ __forceinline__ vf2 pk_sub_f32(vf2 a, vf2 b) {
+  vf2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+#define VI_AS_LDS __attribute__((address_space(3)))
+#define VI_AS_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float4 lds_f4(const float *p) {
+  const vf4 v = *(const VI_AS_LDS vf4 *)(const VI_AS_LDS float *)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 lds_u4(const uint32_t *p) {
+  const vu4 v = *(const VI_AS_LDS vu4 *)(const VI_AS_LDS uint32_t *)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 glb_f4(const float4 *p) {
+  const vf4 v = *(const VI_AS_GLOBAL vf4 *)(const VI_AS_GLOBAL float *)reinterpret_cast<const float *>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 glb_u4(const uint4 *p) {
+  const vu4 v = *(const VI_AS_GLOBAL vu4 *)(const VI_AS_GLOBAL uint32_t *)reinterpret_cast<const uint32_t *>(p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // exact distance of one (query row, stored vector) pair, one lane per pair (src/utils.rs:28-30).  The query row sits
 // in LDS (every lane reads the same address: a broadcast, no vector-memory slot), so all eight loads in flight per
 // lane are the stored vector's
 __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv, uint32_t dim) {
-  const float4 *xq = reinterpret_cast<const float4 *>(qrow);
   float acc = 0.0f;
   const uint32_t nquad = dim >> 2;
   uint32_t qd = 0;
   for (; qd + 8 <= nquad; qd += 8) {
     float4 x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = xv[(size_t)(qd + i) * kWave];
+    for (int i = 0; i < 8; ++i) x[i] = glb_f4(xv + (size_t)(qd + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float4 qq = xq[qd + i];
+      const float4 qq = lds_f4(qrow + 4 * (qd + i));
       sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
     }
   }
   for (; qd < nquad; ++qd) {
-    const float4 qq = xq[qd];
-    const float4 xx = xv[(size_t)qd * kWave];
+    const float4 qq = lds_f4(qrow + 4 * qd);
+    const float4 xx = glb_f4(xv + (size_t)qd * kWave);
     sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
   }
   return acc;
@@ -1041,23 +1072,22 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
 
 // the same sum for a vector stored as dim consecutive floats (coarse table, rows_from_blocks_kernel)
 __device__ __forceinline__ float exact_pair_row(const float *qrow, const float4 *xr, uint32_t dim) {
-  const float4 *xq = reinterpret_cast<const float4 *>(qrow);
   float acc = 0.0f;
   const uint32_t nquad = dim >> 2;
   uint32_t qd = 0;
   for (; qd + 8 <= nquad; qd += 8) {
     float4 x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = xr[qd + i];
+    for (int i = 0; i < 8; ++i) x[i] = glb_f4(xr + qd + i);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float4 qq = xq[qd + i];
+      const float4 qq = lds_f4(qrow + 4 * (qd + i));
       sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
     }
   }
   for (; qd < nquad; ++qd) {
-    const float4 qq = xq[qd];
-    const float4 xx = xr[qd];
+    const float4 qq = lds_f4(qrow + 4 * qd);
+    const float4 xx = glb_f4(xr + qd);
     sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
   }
   return acc;
@@ -1069,11 +1099,11 @@ __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 
   float acc = 0.0f;
   const uint32_t npiece = (dim + 7u) >> 3;  // (dim % 4 == 0: the last piece may hold 4 dimensions)
   auto piece = [&](const uint4 &x, uint32_t p) {
-    const float4 q0 = *reinterpret_cast<const float4 *>(qrow + 8 * p);
+    const float4 q0 = lds_f4(qrow + 8 * p);
     sq_add(acc, q0.x, __uint_as_float(x.x << 16)); sq_add(acc, q0.y, __uint_as_float(x.x & 0xFFFF0000u));
     sq_add(acc, q0.z, __uint_as_float(x.y << 16)); sq_add(acc, q0.w, __uint_as_float(x.y & 0xFFFF0000u));
     if (8 * p + 4 < dim) {
-      const float4 q1 = *reinterpret_cast<const float4 *>(qrow + 8 * p + 4);
+      const float4 q1 = lds_f4(qrow + 8 * p + 4);
       sq_add(acc, q1.x, __uint_as_float(x.z << 16)); sq_add(acc, q1.y, __uint_as_float(x.z & 0xFFFF0000u));
       sq_add(acc, q1.z, __uint_as_float(x.w << 16)); sq_add(acc, q1.w, __uint_as_float(x.w & 0xFFFF0000u));
     }
@@ -1082,18 +1112,18 @@ __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 
   for (; p + 8 <= npiece; p += 8) {
     uint4 x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = xh[(size_t)(p + i) * kWave];
+    for (int i = 0; i < 8; ++i) x[i] = glb_u4(xh + (size_t)(p + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(x[i], p + i);
   }
   for (; p + 4 <= npiece; p += 4) {  // (a half round: D = 96 has 6 / 12 pieces)
     uint4 x[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = xh[(size_t)(p + i) * kWave];
+    for (int i = 0; i < 4; ++i) x[i] = glb_u4(xh + (size_t)(p + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece(x[i], p + i);
   }
-  for (; p < npiece; ++p) piece(xh[(size_t)p * kWave], p);
+  for (; p < npiece; ++p) piece(glb_u4(xh + (size_t)p * kWave), p);
   return acc;
 }
 
@@ -1102,7 +1132,7 @@ __device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *x
   float acc = 0.0f;
   const uint32_t npiece = (dim + 15u) >> 4;  // (dim % 4 == 0: the last piece may hold 4, 8 or 12 dimensions)
   auto word = [&](uint32_t w, uint32_t e) {   // 4 dimensions starting at e
-    const float4 q = *reinterpret_cast<const float4 *>(qrow + e);
+    const float4 q = lds_f4(qrow + e);
     sq_add(acc, q.x, (float)(w & 0xFFu)); sq_add(acc, q.y, (float)((w >> 8) & 0xFFu));
     sq_add(acc, q.z, (float)((w >> 16) & 0xFFu)); sq_add(acc, q.w, (float)(w >> 24));
   };
@@ -1117,18 +1147,18 @@ __device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *x
   for (; p + 8 <= npiece; p += 8) {
     uint4 x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+    for (int i = 0; i < 8; ++i) x[i] = glb_u4(xb + (size_t)(p + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(x[i], p + i);
   }
   for (; p + 4 <= npiece; p += 4) {  // (a half round: D = 96 has 6 / 12 pieces)
     uint4 x[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+    for (int i = 0; i < 4; ++i) x[i] = glb_u4(xb + (size_t)(p + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece(x[i], p + i);
   }
-  for (; p < npiece; ++p) piece(xb[(size_t)p * kWave], p);
+  for (; p < npiece; ++p) piece(glb_u4(xb + (size_t)p * kWave), p);
   return acc;
 }
 
@@ -1141,7 +1171,7 @@ __device__ __forceinline__ float exact_pair_u8_int(const uint32_t *qb, uint32_t 
   const uint32_t npiece = (dim + 15u) >> 4;
   uint32_t dot = 0u, xx = 0u;
   auto piece = [&](const uint4 &x, uint32_t p) {
-    const uint4 q = *reinterpret_cast<const uint4 *>(qb + 4 * p);
+    const uint4 q = lds_u4(qb + 4 * p);
     dot = __builtin_amdgcn_udot4(q.x, x.x, dot, false); xx = __builtin_amdgcn_udot4(x.x, x.x, xx, false);
     dot = __builtin_amdgcn_udot4(q.y, x.y, dot, false); xx = __builtin_amdgcn_udot4(x.y, x.y, xx, false);
     dot = __builtin_amdgcn_udot4(q.z, x.z, dot, false); xx = __builtin_amdgcn_udot4(x.z, x.z, xx, false);
@@ -1151,11 +1181,11 @@ __device__ __forceinline__ float exact_pair_u8_int(const uint32_t *qb, uint32_t 
   for (; p + 8 <= npiece; p += 8) {
     uint4 x[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = xb[(size_t)(p + i) * kWave];
+    for (int i = 0; i < 8; ++i) x[i] = glb_u4(xb + (size_t)(p + i) * kWave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(x[i], p + i);
   }
-  for (; p < npiece; ++p) piece(xb[(size_t)p * kWave], p);
+  for (; p < npiece; ++p) piece(glb_u4(xb + (size_t)p * kWave), p);
   return (float)(qn + xx - 2u * dot);  // (an integer below 2^24: exact)
 }
 
@@ -1202,6 +1232,65 @@ __device__ __attribute__((noinline)) Top exact_batch_row_fn(Top sel, const float
   float d = INFINITY;
   if (live) d = exact_pair_row(qrow, xr, dim);
   sel.offer_bulk(d, live ? key : kNoPos, K);
+  return sel;
+}
+
+// Up to 64 rows of a row-major table (one per lane, `cnt` of them live) against the query, with the ROWS FETCHED BY THE
+// WHOLE WAVE: a lane reading its own row asks the texture unit for 64 different cache lines per load instruction (one
+// 16-byte piece of each) — 2 048 line requests for 64 rows of 128 floats, and the address pipe, not the arithmetic, set
+// the pace of the coarse select.  Here four lanes fetch 64 consecutive bytes of a row (16 rows per instruction, 512
+// requests in all) straight into LDS (LDS-DMA: no registers in between, two chunks of 16 dimensions in flight), and
+// every lane then runs the reference's chain (utils.rs:28-30) over its own row as before.  A DMA instruction writes
+// lane l's 16 bytes at LDS offset 16 l, so a row's four pieces sit 64 bytes apart from the next row's — a lane per row
+// reading piece p would hit the same banks eight times over; lane l therefore fetches piece (l & 3) ^ ((l >> 3) & 3)
+// and row r reads its piece p from slot 4 r + (p ^ ((r >> 1) & 3)): conflict free.
+// dim % 16 == 0; stage: kStageFloats floats of LDS per wave (a ring of two chunks); the waits are counted by hand
+// (the copies are inline asm, invisible to the compiler's own counting: mfma_bf16.hpp).
+constexpr uint32_t kStageFloats = 2048;
+template <class Top>
+__device__ __attribute__((noinline)) Top exact_batch_rows_staged_fn(Top sel, const float *qrow, const float4 *rows, uint32_t nrows, uint32_t dim,
+                                                                    uint32_t cnt, uint32_t pos, int K, float *stage) {
+  const uint32_t lane = threadIdx.x & 63u, r0 = lane >> 2, piece = (lane & 3u) ^ ((lane >> 3) & 3u);
+  const uint32_t nquad = dim >> 2, nch = nquad >> 2;
+  const VI_AS_LDS vf4 *xq = (const VI_AS_LDS vf4 *)(const VI_AS_LDS float *)qrow;
+  const uint32_t sbase = (uint32_t)(size_t)(VI_AS_LDS float *)stage;
+  const float4 *src[4];  // piece `piece` of the rows r0 + 16 j (rows beyond cnt: the last live one again)
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j)
+    src[j] = rows + (size_t)min((uint32_t)__shfl((int)pos, (int)min(r0 + 16u * j, cnt - 1u)), nrows - 1u) * nquad + piece;
+  auto issue = [&](uint32_t c) {  // chunk c -> ring slot c & 1: four copies of 1 KiB
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) glds16_at(src[j] + 4u * c, sbase + (c & 1u) * 4096u + j * 1024u);
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (whatever the caller left in flight: the counts below are this function's)
+  issue(0u);
+  if (nch > 1u) issue(1u);
+  const uint32_t swz = (lane >> 1) & 3u;
+  float acc = 0.0f;
+#pragma unroll 1
+  for (uint32_t c = 0; c < nch; ++c) {
+    if (c + 1u < nch) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const VI_AS_LDS vf4 *rd = (const VI_AS_LDS vf4 *)((const VI_AS_LDS float *)stage + (c & 1u) * 1024u + lane * 16u);
+    const vf4 x0 = rd[0u ^ swz], x1 = rd[1u ^ swz], x2 = rd[2u ^ swz], x3 = rd[3u ^ swz];
+    const vf4 q0 = xq[4u * c], q1 = xq[4u * c + 1u], q2 = xq[4u * c + 2u], q3 = xq[4u * c + 3u];
+    // (differences and squares four at a time — packed f32 instructions round every component as the scalar ones do;
+    //  the sum stays the reference's sequential chain)
+#define VI_PK_QUAD(QQ, XX)                                                         \
+  {                                                                                \
+    const vf2 ta = pk_sub_f32(QQ.xy, XX.xy), tb = pk_sub_f32(QQ.zw, XX.zw);        \
+    const vf2 sa = ta * ta, sb = tb * tb;                                          \
+    acc = acc + sa.x; acc = acc + sa.y; acc = acc + sb.x; acc = acc + sb.y;        \
+  }
+    VI_PK_QUAD(q0, x0) VI_PK_QUAD(q1, x1) VI_PK_QUAD(q2, x2) VI_PK_QUAD(q3, x3)
+#undef VI_PK_QUAD
+    if (c + 2u < nch) {  // the slot's values are in registers (the chain above consumed them): refill it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue(c + 2u);
+    }
+  }
+  const bool live = lane < cnt && pos < nrows;
+  sel.offer_bulk(live ? acc : INFINITY, live ? pos : kNoPos, K);
   return sel;
 }
 
@@ -1634,6 +1723,7 @@ struct CoarseSelectArgs {
   // record counts of the list phase (what pair_groups_kernel computes otherwise)
   uint32_t list_segb0;
   uint32_t *rel, *qtot;
+  uint32_t staged;  // single rows fetched by the whole wave through LDS (exact_batch_rows_staged_fn); VI_COARSE_STAGED=0: a row per lane
 };
 
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
@@ -1685,21 +1775,30 @@ __global__ void __launch_bounds__(256, 4) coarse_select_kernel(CoarseSelectArgs 
 // all 8 when its second minimum is at or below the threshold too.  No group records, no refinement rounds: at P = 32
 // about 40 exact distances per query decide the probe list.
 constexpr uint32_t kDirectBlocks = 256;
-constexpr uint32_t kWholeCap = 64;  // whole 8-row sub-blocks waiting for their exact distances (per wave)
 __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectArgs a) {
-  __shared__ uint32_t s_pick[4][kPickCap], s_whole[4][kWholeCap];
+  __shared__ uint32_t s_pick[4][kPickCap];
   __shared__ __attribute__((aligned(16))) float s_q[4][kNarrowDim];  // (the coarse step runs here only for D <= 128)
+  __shared__ __attribute__((aligned(16))) float s_stage[4][kStageFloats];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * 4 + wave;
   if (q >= a.nq) return;
   const SelectCommon &c = a.c;
-  uint32_t *pick = s_pick[wave], *whole = s_whole[wave];
+  uint32_t *pick = s_pick[wave];
   float *qlds = s_q[wave];
   const uint64_t below = (1ull << lane) - 1ull;
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // (diagnostic, VI_FILTER_STATS=2: s_memtime ticks per stage, summed over the queries into dbg[150..155])
+  unsigned long long tk = c.dbg ? __builtin_amdgcn_s_memtime() : 0ull, tks[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) {
+    if (c.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tks[i] += now - tk;
+      tk = now;
+    }
   };
   float qn = 0.0f;
   for (uint32_t e = lane; e < c.dim; e += kWave) {
@@ -1711,13 +1810,13 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) qn += __shfl_xor(qn, o);
   lds_sync();
+  lap(0);
   const float E = c.e_scale * (qn * (1.0f + c.gamma) + 2.0f * c.xmax2);
   const bool distrust = !(qn < 1.0e30f);  // see select_body
   const uint32_t K = a.P, nblk = (a.nlists + kWave - 1) / kWave, nrec = 4u * nblk;  // records: (block, tile, lane half)
   const size_t base = (size_t)(q / c.gq) * nblk * (4u * c.gq) + (q % c.gq);
   constexpr uint32_t kPer = kDirectBlocks * 4 / kWave;  // records per lane
-  // (min of sub-block 0 with its row, its second min, the same of sub-block 1); read twice — for the bound, then for
-  // the flags (from L2 the second time) — rather than kept in 64 registers: one more wave per SIMD
+  // (min of sub-block 0 with its row, its second min, the same of sub-block 1)
   auto record = [&](uint32_t i) {
     const uint32_t rec = i * kWave + lane;  // block rec >> 2, tile (rec >> 1) & 1, lane half rec & 1
     float4 r = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
@@ -1730,12 +1829,16 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   // or below the K-th smallest of the 64 lane minima — one 64-lane sort instead of a running top-K over all the minima
   // (K <= 64; the bound sits a few ranks above the exact K-th minimum, which costs a few more single-row evaluations)
   float lm = INFINITY;
+  float rb1[kPer][2], rb2[kPer][2];  // (kept for the flags below: 16 registers; a second read from L2 was a round trip per query)
 #pragma unroll
-  for (uint32_t i = 0; i < kPer; ++i)
+  for (uint32_t i = 0; i < kPer; ++i) {
+    rb1[i][0] = rb1[i][1] = rb2[i][0] = rb2[i][1] = INFINITY;
     if (i * kWave < nrec) {
       const float4 r = record(i);
       lm = min3_raw(lm, r.x, r.z);
+      rb1[i][0] = r.x; rb2[i][0] = r.y; rb1[i][1] = r.z; rb2[i][1] = r.w;
     }
+  }
   FastTopK s1;
   s1.init();
   s1 = offer_bulk_fn(s1, lm, (uint32_t)lane, (int)K);
@@ -1747,9 +1850,10 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
       thr = mk + (2.0f * E + 3.0f * c.gamma * scale) * 1.001f + 1e-30f;
     }
   }
+  lap(1);
   FastTopK sel;
   sel.init();
-  uint32_t npick = 0, nwhole = 0;
+  uint32_t npick = 0;
   auto exact_rows = [&](bool live, uint32_t pos) {
     live = live && pos < a.nlists && !(c.xmode & 1u);
     sel = exact_batch_fn(sel, qlds, c.blocks + ((size_t)((live ? pos : 0u) / kWave) * c.dq) * kWave + (pos % kWave), c.dim, live, pos,
@@ -1759,13 +1863,17 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   auto sub_row = [&](uint32_t rec, uint32_t s, uint32_t e) {
     return (rec >> 2) * kWave + subblock_vector(8u * s + e, (rec >> 1) & 1u, rec & 1u, c.image_order != 0u);
   };
+  uint32_t n_single = 0, n_whole = 0;  // (VI_FILTER_STATS=2: rows evaluated alone / whole 8-row sub-blocks)
   auto drain_singles = [&]() {
     while (npick > 0) {
       const uint32_t cnt = npick >= (uint32_t)kWave ? (uint32_t)kWave : npick;
       npick -= cnt;
+      n_single += cnt;
       bool live = (uint32_t)lane < cnt;
       const uint32_t pos = live ? pick[npick + lane] : 0u;
-      if (a.cent_rows) {  // one centroid per lane, each its own whole cache lines
+      if (a.cent_rows && a.staged) {  // one centroid per lane, the rows fetched by the whole wave
+        if (!(c.xmode & 1u)) sel = exact_batch_rows_staged_fn(sel, qlds, a.cent_rows, a.nlists, c.dim, cnt, pos, (int)K, s_stage[wave]);
+      } else if (a.cent_rows) {  // one centroid per lane, each its own whole cache lines
         live = live && pos < a.nlists && !(c.xmode & 1u);
         sel = exact_batch_row_fn(sel, qlds, a.cent_rows + (size_t)(live ? pos : 0u) * (c.dim / 4), c.dim, live, pos, (int)K);
       } else {
@@ -1773,19 +1881,63 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
       }
     }
   };
-  auto drain_whole = [&]() {  // 8 sub-blocks x 8 rows per round
-    while (nwhole > 0) {
-      const uint32_t cnt = nwhole >= 8u ? 8u : nwhole;
-      nwhole -= cnt;
-      const uint32_t rq = (uint32_t)lane >> 3;
-      const bool live = rq < cnt;
-      const uint32_t ck = live ? whole[nwhole + rq] : 0u;  // (record << 1) | sub-block
-      exact_rows(live, sub_row(ck >> 1, ck & 1u, (uint32_t)lane & 7u));
+  // Which rows go to the exact evaluation: of a sub-block whose minimum is at or below thr the row of that minimum, all
+  // eight when its second minimum is too.  A lane counts the rows of its eight sub-blocks, one scan over the wave gives
+  // every lane its place in the list, one LDS round writes them (a ballot, a count and an LDS round per sub-block column
+  // and kind — sixteen of each — were a fifth of the kernel).  More rows than the list holds (a distrusted query flags
+  // everything): the ballot loop below, which drains the list as it fills.
+  bool listed = false;
+  if (!(c.xmode & 16u)) {
+    uint32_t cls = 0, rowbits = 0, mine = 0;  // 2 bits per sub-block: 0 none, 1 the row of the minimum, 2 all eight; 3 bits: that row
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i)
+      if (i * kWave < nrec) {
+        const uint32_t rec = i * kWave + lane;
+#pragma unroll
+        for (uint32_t s2 = 0; s2 < 2; ++s2) {
+          const bool cand = rec < nrec && !(rb1[i][s2] > thr);
+          const bool all8 = cand && (!(rb2[i][s2] > thr) || distrust);
+          const uint32_t k = all8 ? 2u : (cand ? 1u : 0u);
+          cls |= k << (2u * (2u * i + s2));
+          rowbits |= (__float_as_uint(rb1[i][s2]) & 7u) << (3u * (2u * i + s2));
+          mine += all8 ? 8u : (cand ? 1u : 0u);
+        }
+      }
+    uint32_t incl = mine;  // inclusive scan over the lanes (DPP: shifts within rows of 16, then the row totals)
+    incl += dpp_u32<0x111>(0u, incl);  // row_shr:1
+    incl += dpp_u32<0x112>(0u, incl);  // row_shr:2
+    incl += dpp_u32<0x114>(0u, incl);  // row_shr:4
+    incl += dpp_u32<0x118>(0u, incl);  // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+    const uint32_t total = readlane_u(incl, 63);
+    if (total <= kPickCap) {
+      uint32_t at = incl - mine;
+#pragma unroll
+      for (uint32_t sb = 0; sb < 2u * kPer; ++sb) {
+        const uint32_t k = (cls >> (2u * sb)) & 3u, rec = (sb >> 1) * kWave + lane;
+        if (k == 1u) {
+          pick[at] = sub_row(rec, sb & 1u, (rowbits >> (3u * sb)) & 7u);
+          at += 1u;
+        } else if (k == 2u) {
+#pragma unroll
+          for (uint32_t e = 0; e < 8u; ++e) pick[at + e] = sub_row(rec, sb & 1u, e);
+          at += 8u;
+          n_whole += 1u;  // (per lane here; summed below when the counters are on)
+        }
+      }
+      npick = total;
+      listed = true;
+      lds_sync();
+      if (c.dbg) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_whole += (uint32_t)__shfl_xor((int)n_whole, o);
+      }
     }
-  };
+  }
 #pragma unroll
   for (uint32_t i = 0; i < kPer; ++i)
-    if (i * kWave < nrec) {
+    if (i * kWave < nrec && !(c.xmode & 16u) && !listed) {
       const uint32_t rec = i * kWave + lane;
       const float4 Ri = record(i);
       const float b1[2] = {Ri.x, Ri.z}, b2[2] = {Ri.y, Ri.w};
@@ -1803,21 +1955,34 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
           lds_sync();
         }
         m = __ballot(all8);
-        if (m) {
-          const uint32_t cnt = (uint32_t)__popcll(m);
-          if (nwhole + cnt > kWholeCap) drain_whole();
-          if (all8) whole[nwhole + (uint32_t)__popcll(m & below)] = (rec << 1) | s2;
-          nwhole += cnt;
-          lds_sync();
+        if (m) {  // all 8 rows of the sub-block: into the same list (they used to wait for rounds of their own — a second exact
+          // round and a second merge per query for 1.6 sub-blocks on average, a third of the kernel's instructions)
+          // (32 lanes at a time: their 256 rows fill the list exactly — a distrusted query flags every sub-block)
+#pragma unroll
+          for (uint32_t half = 0; half < 2u; ++half) {
+            const uint64_t mh = m & (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+            if (!mh) continue;
+            const uint32_t cnt = 8u * (uint32_t)__popcll(mh);
+            if (npick + cnt > kPickCap) drain_singles();
+            if (all8 && ((uint32_t)lane >> 5) == half) {
+              const uint32_t at = npick + 8u * (uint32_t)__popcll(mh & below);
+#pragma unroll
+              for (uint32_t e = 0; e < 8u; ++e) pick[at + e] = sub_row(rec, s2, e);
+            }
+            npick += cnt;
+            n_whole += cnt >> 3;
+            lds_sync();
+          }
         }
       }
     }
-  drain_whole();
+  lap(2);
   drain_singles();
+  lap(3);
   // ---- the same tail as coarse_select_kernel: probes, candidate order, histogram, record offsets of the list phase ----
   const uint32_t found = (uint32_t)__popcll(__ballot((uint32_t)lane < a.P && sel.ent_p(0) != kNoPos));
   const uint32_t mylist = (uint32_t)lane < found ? sel.ent_p(0) : kNoPos;
-  const uint32_t g = probe_candidate_order(lane, found, mylist, a.list_shard);
+  const uint32_t g = (c.xmode & 32u) ? (uint32_t)lane : probe_candidate_order(lane, found, mylist, a.list_shard);
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
@@ -1836,6 +2001,12 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   }
   if ((uint32_t)lane < a.P) a.rel[(size_t)q * a.P + lane] = ig - ng;
   if (lane == 63) a.qtot[q] = ig;
+  lap(4);
+  if (c.dbg && lane == 0 && (q & 63u) == 0u) {  // (every 64th query: 70 000 same-address atomics would be most of the kernel)
+    for (int i = 0; i < 5; ++i) atomicAdd(&c.dbg[150 + i], tks[i]);
+    atomicAdd(c.dbg + 6, (unsigned long long)n_single);
+    atomicAdd(c.dbg + 7, (unsigned long long)n_whole);
+  }
 }
 
 // a ring of three tile buffers (two tiles in flight per workgroup) for the hi-planes-only list ranking: measured equal to
@@ -2248,6 +2419,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
                        (uint32_t)nlists, segb, recs, ix.list_shard.p, ix.list_len.p, ws.probes.p, ws.gorder.p,
                        ws.cnt.p, qmajor ? 1u : 0u, nullptr, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_COARSE_ROWS"); if (ix.cent_rows.p && !(e && *e == '0')) a.cent_rows = (const float4 *)ix.cent_rows.p; }
+    { const char *e = getenv("VI_COARSE_STAGED"); a.staged = (e && *e == '0') || (ix.dim & 15u) ? 0u : 1u; }
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
     if (direct) a.c.e_scale += (float)(1.01 * std::ldexp(1.0, -20));  // the row index rides in 3 mantissa bits of the minima
@@ -2534,6 +2706,10 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     VI_HIP(hipMemcpyAsync(dbg, ws.stats.p, sizeof(dbg), hipMemcpyDeviceToHost, st));
     VI_HIP(hipMemcpyAsync(tks, ws.stats.p + 150, sizeof(tks), hipMemcpyDeviceToHost, st));
     VI_HIP(hipStreamSynchronize(st));
+    if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '2')
+      fprintf(stderr, "coarse select ticks (every 64th query): query row %llu, records + bound %llu, flags (+ rounds a full list forces) %llu, exact rounds %llu, tail %llu; rows %llu "
+              "of which in whole sub-blocks %llu\n", (unsigned long long)tks[0], (unsigned long long)tks[1], (unsigned long long)tks[2],
+              (unsigned long long)tks[3], (unsigned long long)tks[4], (unsigned long long)dbg[6], 8ull * (unsigned long long)dbg[7]);
     if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
       fprintf(stderr, "select ticks: records -> LDS %llu, threshold %llu, refinement %llu, scan of pair records (+ exact rounds it triggers) %llu, "
               "last exact rounds %llu\n", (unsigned long long)tks[0], (unsigned long long)tks[1], (unsigned long long)tks[2],

@@ -200,16 +200,18 @@ __device__ __forceinline__ uint32_t probe_candidate_order(int lane, uint32_t fou
                                                           const uint32_t *list_shard) {
   const bool live = (uint32_t)lane < found;
   const uint32_t shard = live ? list_shard[mylist] : kNoPos;
-  uint32_t fa = (uint32_t)lane;
-  for (uint32_t i = 0; i < found; ++i) {
-    const uint32_t s = readlane_u(shard, (int)i);
-    if (live && s == shard && i < fa) fa = i;
-  }
-  const uint32_t okey = live ? fa * 64u + (uint32_t)lane : kNoPos;
-  uint32_t g = 0;
-  for (uint32_t i = 0; i < found; ++i) {
-    const uint32_t k2 = readlane_u(okey, (int)i);
-    g += (k2 < okey) ? 1u : 0u;
+  // one step per DISTINCT shard, in order of first appearance (the lowest lane still waiting leads): its probes take the
+  // next ranks in lane order.  (Two passes over all probes with a readlane each were an eighth of the coarse select.)
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint64_t todo = __ballot(live);
+  uint32_t g = found, base = 0;  // (lanes without a probe: `found`, as the rank under the key kNoPos)
+  while (todo) {
+    const uint32_t s = readlane_u(shard, __builtin_ctzll(todo));
+    const bool mine = live && shard == s;
+    const uint64_t same = __ballot(mine);
+    if (mine) g = base + (uint32_t)__popcll(same & below);
+    base += (uint32_t)__popcll(same);
+    todo &= ~same;
   }
   return g;
 }
