@@ -998,6 +998,8 @@ struct SelectCommon {
   const uint4 *u8_nat;      // 8-bit descriptors: one byte per dimension (u8_natural_kernel), else null
   uint32_t wave_order;      // pair records in the streaming kernel's wave order (scan.hpp: seg_records), else pair order
   uint32_t xmode;           // ablation knob (VI_SELECT_XMODE, wrong results): 1 no exact evaluation, 2 no stage 2, 4 no stage 1b
+  uint32_t dbg_mask;        // counters of the queries with (q & dbg_mask) == 0 only (VI_FILTER_STATS=4: every 64th — ten thousand
+                            // waves adding to the same few addresses are most of the kernel's time, which the stage clocks then measure)
   const float *mu;          // centre of the ranking images (rank values are those of q - mu against v - mu), or null
   uint32_t trunc;           // real-valued lists ranked from their hi planes: 1 queries hi + lo, 2 queries' hi plane only; 0 otherwise
   float rho_max, vmax;      // ... max |v - hi(v)| and max |v| over the lists (rounded up)
@@ -1628,7 +1630,7 @@ __device__ __forceinline__ void select_body(const SelectCommon &c, uint32_t q, s
   lap(3);
   drain_pick();
   lap(4);
-  if (c.dbg && lane == 0) {
+  if (c.dbg && lane == 0 && (q & c.dbg_mask) == 0u) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) atomicAdd(&c.dbg[150 + i], tks[i]);
     atomicAdd(&c.dbg[6], (unsigned long long)n_exact);
@@ -1682,15 +1684,15 @@ __global__ void __launch_bounds__(256, 4) select_kernel(SelectArgs a) {
                    s_lcache[wave], s_qrows + (size_t)wave * a.c.dim, sel, s_qbytes[wave]);
   // entry e of lane i holds result 64e + i: map the candidate-order rank g back to the probe rank r
   uint32_t found = 0;
+  // probe rank of candidate-order rank g: lane r pushes r to lane g(r) (the ranks of a query's probes are a permutation of
+  // 0 .. found-1; lanes without a probe push to themselves, at or above found) — one crossbar push instead of a readlane
+  // and a compare per probe and result entry
+  const uint32_t inv = (uint32_t)__builtin_amdgcn_ds_permute((int)(4u * (mylist != kNoPos ? pr.g : (uint32_t)lane)), lane);
 #pragma unroll
   for (int e = 0; e < Top::kEntries; ++e) {
     const uint32_t key = sel.ent_p(e), idx = 64u * (uint32_t)e + (uint32_t)lane;
     const uint32_t g = key >> kPosBits, pos = key & kPosMask;
-    uint32_t r = 0;
-    for (uint32_t rr = 0; rr < a.P; ++rr) {
-      const uint32_t gv = readlane_u(pr.g, (int)rr);
-      if (gv == g) r = rr;
-    }
+    const uint32_t r = (uint32_t)__shfl((int)inv, (int)(g & 63u));
     const bool have = idx < a.k && key != kNoPos;
     found += (uint32_t)__popcll(__ballot(have));
     const uint32_t fbk = (uint32_t)__shfl((int)pr.fb, (int)r);
@@ -2129,6 +2131,7 @@ SelectCommon select_common(const DeviceIndex &ix, const float *Qd, const float4 
   // per-wave counters go to two addresses: 2 same-address atomics per query cost more than the whole select, so
   // they are a diagnostic (VI_FILTER_STATS=1), not part of the normal path
   c.dbg = getenv("VI_FILTER_STATS") ? (unsigned long long *)ix.cur().ws.stats.p : nullptr;
+  { const char *e = getenv("VI_FILTER_STATS"); c.dbg_mask = e && *e == '4' ? 63u : 0u; }
   { const char *xm = getenv("VI_SELECT_XMODE"); c.xmode = xm ? (uint32_t)atoi(xm) : 0u; }
   return c;
 }
@@ -2710,12 +2713,12 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
       fprintf(stderr, "coarse select ticks (every 64th query): query row %llu, records + bound %llu, flags (+ rounds a full list forces) %llu, exact rounds %llu, tail %llu; rows %llu "
               "of which in whole sub-blocks %llu\n", (unsigned long long)tks[0], (unsigned long long)tks[1], (unsigned long long)tks[2],
               (unsigned long long)tks[3], (unsigned long long)tks[4], (unsigned long long)dbg[6], 8ull * (unsigned long long)dbg[7]);
-    if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
+    if (const char *e = getenv("VI_FILTER_STATS"); e && (*e == '3' || *e == '4'))
       fprintf(stderr, "select ticks: records -> LDS %llu, threshold %llu, refinement %llu, scan of pair records (+ exact rounds it triggers) %llu, "
               "last exact rounds %llu\n", (unsigned long long)tks[0], (unsigned long long)tks[1], (unsigned long long)tks[2],
               (unsigned long long)tks[3], (unsigned long long)tks[4]);
     stt.filter_rechecked = dbg[6]; stt.filter_accepted = dbg[7];
-    if (const char *e = getenv("VI_FILTER_STATS"); e && *e == '3')
+    if (const char *e = getenv("VI_FILTER_STATS"); e && (*e == '3' || *e == '4'))
       fprintf(stderr, "select stats: exact %llu groups_scanned %llu queries_with_full_group %llu full_groups %llu sub_blocks %llu\n",
               (unsigned long long)dbg[6], (unsigned long long)dbg[7], (unsigned long long)dbg[8], (unsigned long long)dbg[9],
               (unsigned long long)dbg[10]);

@@ -116,6 +116,7 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t k, int src) {
 struct FastTopK {
   uint64_t key, thr;  // thr = key of entry K-1 (wave-uniform)
   static constexpr int kEntries = 1;
+  static constexpr int kSeqInsert = 8;  // newcomers inserted one by one up to here
   static constexpr uint64_t kEmpty = ((uint64_t)0xFF800000u << 32) | 0xFFFFFFFFu;  // (+inf, kNoPos)
   __device__ __forceinline__ void init() { key = kEmpty; thr = kEmpty; }
   __device__ __forceinline__ float kth(int K) const { return sortable_f32((uint32_t)(readlane_u64(key, K - 1) >> 32)); }
@@ -129,11 +130,16 @@ struct FastTopK {
     const uint64_t mask = __ballot(pass);
     if (!mask) return;
     v = pass ? v : kEmpty;
-    if (__popcll(mask) == 1) {  // one newcomer: entries above it move up a lane
-      const uint64_t c = readlane_u64(v, __builtin_ctzll(mask));
-      const uint32_t ulo = dpp_u32<0x138>(0u, (uint32_t)key), uhi = dpp_u32<0x138>(0u, (uint32_t)(key >> 32));  // wave_shr:1
-      const uint64_t up = lane ? (((uint64_t)uhi << 32) | ulo) : 0ull;
-      key = key > c ? (up > c ? up : c) : key;
+    if (__popcll(mask) <= kSeqInsert) {  // a few newcomers, one after the other: entries above each move up a lane
+      // (~10 instructions each against ~300 for the sort and merge below; once the list has filled, a round of 64
+      //  offers brings K * 64 / (offered so far) newcomers on average — a handful from the second round on)
+      for (uint64_t m = mask; m; m &= m - 1ull) {
+        const uint64_t c = readlane_u64(v, __builtin_ctzll(m));
+        // wave_shr:1 — lane 0 has no source and keeps the `old` operand, 0: below every key
+        const uint32_t ulo = dpp_u32<0x138>(0u, (uint32_t)key), uhi = dpp_u32<0x138>(0u, (uint32_t)(key >> 32));
+        const uint64_t up = ((uint64_t)uhi << 32) | ulo;
+        key = key > c ? (up > c ? up : c) : key;
+      }
     } else {
       wave_sort_u64(v, lane);
       const uint64_t rv = exchange_u64<Ex::M63>(v, lane);  // descending: min(list, reversed offer) holds the 64 smallest
