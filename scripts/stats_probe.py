@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Diagnostic: the select kernels' counters and stage clocks at the headline point (C2, nprobe 32, 10 000 queries).
+    python scripts/stats_probe.py 2    coarse select: rows evaluated exactly, sampled stage clocks
+    python scripts/stats_probe.py 3    list select: counters of every query (the atomics distort the clocks)
+    python scripts/stats_probe.py 4    list select: counters and stage clocks of every 64th query"""
 import os, sys
 os.environ["VI_FILTER_STATS"] = sys.argv[1]
 ROOT = "/root/repo"

@@ -231,3 +231,24 @@ def test_select_top_k_sorts_without_the_lds_crossbar(asm):
         assert "ds_bpermute" not in body, f"{name}: the sorting network goes through the LDS crossbar again"
         assert "v_permlane32_swap" in body and "v_permlane16_swap" in body and "_dpp" in body, name
         assert len(re.findall(r"v_cmp_\w+_u64", body)) >= 27, name   # one 64-bit compare per compare-exchange step
+
+
+def test_exact_evaluation_pieces_keep_their_address_spaces_and_counted_waits(asm):
+    """The exact-evaluation pieces of the select kernels are real (noinline) functions: their pointer arguments are
+    generic, and without the address-space casts every access — the query row in LDS included — is a flat_load through
+    the vector-memory address pipe.  The staged row evaluation of the coarse select also counts its LDS-DMA copies by
+    hand (vmcnt(4) / vmcnt(0)): correct only while those copies are the function's ONLY vector-memory operations."""
+    fns = _kernel_bodies(asm, r"_ZN2vi12_GLOBAL__N_1\d+exact_batch_\w*fnINS_(8FastTopK|10FastTop128)EEET_\w+")
+    assert len(fns) >= 8, sorted(fns)
+    for name, (body, _) in fns.items():
+        assert not re.search(r"^\s*flat_(load|store)", body, re.M), f"{name}: generic-pointer access"
+        assert not re.search(r"^\s*scratch_(load|store)", body, re.M) or "u8_fn" in name, f"{name}: spills"
+    staged = {n: b for n, (b, _) in fns.items() if "rows_staged" in n}
+    assert len(staged) == 1
+    for name, body in staged.items():
+        assert len(re.findall(r"global_load_lds_dwordx4", body)) >= 12, name          # two chunks up front, one per round
+        assert not re.search(r"^\s*global_load_(?!lds)", body, re.M), f"{name}: a plain global load among the counted copies"
+        assert not re.search(r"^\s*(global_store|global_atomic|scratch_|buffer_)", body, re.M), name
+        assert re.search(r"s_waitcnt vmcnt\(4\)", body) and re.search(r"s_waitcnt vmcnt\(0\)", body), name
+        assert len(re.findall(r"v_pk_add_f32", body)) >= 8 and len(re.findall(r"v_pk_mul_f32", body)) >= 8, name
+        assert not re.search(r"v_(fma|fmac|mad)_f32", body), f"{name}: a fused multiply-add in the reference's unfused chain"

@@ -142,9 +142,13 @@ struct FastTopK {
       }
     } else {
       wave_sort_u64(v, lane);
-      const uint64_t rv = exchange_u64<Ex::M63>(v, lane);  // descending: min(list, reversed offer) holds the 64 smallest
-      key = rv < key ? rv : key;
-      wave_merge_u64(key, lane);
+      if (readlane_u64(key, 0) == kEmpty) {  // an empty list (every first offer): the sorted offer is the list
+        key = v;
+      } else {
+        const uint64_t rv = exchange_u64<Ex::M63>(v, lane);  // descending: min(list, reversed offer) holds the 64 smallest
+        key = rv < key ? rv : key;
+        wave_merge_u64(key, lane);
+      }
     }
     thr = readlane_u64(key, K - 1);
   }
