@@ -334,6 +334,9 @@ vi_status vi_indexer_last_build_stats(const vi_indexer *ix, vi_build_stats *out)
 
 /* stats of the most recent search on this handle (timing collected only if enabled) */
 vi_status vi_indexer_last_stats(const vi_indexer *ix, vi_search_stats *out);
+/* enable: 0 off; 1 HIP events at every phase boundary of a search (ms_total / ms_coarse / ms_group / ms_scan / ms_merge);
+ * 2 around the list-rank kernel only (ms_scan; the others read 0) — every event record is a barrier packet on the search
+ * stream, five of them cost about 0.01 ms per search */
 void vi_indexer_enable_timing(vi_indexer *ix, int enable);
 
 #ifdef __cplusplus

@@ -33,6 +33,7 @@ ap.add_argument("--nprobe", type=int, default=32)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--real-valued", action="store_true", help="VI_FILTER_HI_ONLY=0: the bf16 x 3 ranking real-valued lists take")
+ap.add_argument("--no-timing", action="store_true", help="no phase events on the search stream (the phase times read 0)")
 a = ap.parse_args()
 if a.real_valued:
     os.environ["VI_FILTER_HI_ONLY"] = "0"
@@ -42,7 +43,7 @@ work = os.path.join(tempfile.gettempdir(), f"vi_prof_{os.getuid()}_{a.n}_{a.d}_{
 shutil.rmtree(work, ignore_errors=True)
 idx = vip.build(xb.cpu().numpy(), work, nlist=a.nlist, now_secs=1_700_000_000)
 del xb
-idx.enable_timing(True)
+idx.enable_timing(not a.no_timing)
 D = torch.empty((a.nq, a.k), dtype=torch.float32, device=dev)
 I = torch.empty((a.nq, a.k), dtype=torch.int64, device=dev)
 acc = []

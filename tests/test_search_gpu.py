@@ -222,7 +222,9 @@ def test_generic_path_equals_fast_path(tmp_path, monkeypatch):
 @pytest.mark.parametrize("n,d,nlist,kind", [(20000, 64, 0, "gauss"), (6000, 128, 24, "gauss"), (4000, 96, 0, "gauss"),
                                             (5000, 32, 12, "clustered"), (3000, 8, 40, "grid"), (9000, 100, 30, "sift"),
                                             (40000, 32, 1024, "gauss"), (4000, 32, 10, "offset"),
-                                            (5000, 128, 20, "wide")])
+                                            (5000, 128, 20, "wide"),
+                                            (30000, 20, 1100, "gauss"),       # D % 16 != 0: the coarse select reads a table row per lane
+                                            (36000, 48, 1100, "clustered")])  # ... and fetches them by the whole wave (3 chunks)
 def test_mfma_filter_path_parity(n, d, nlist, kind, tmp_path, monkeypatch):
     """VI_FILTER=1 forces the f32-MFMA rank + exact re-evaluation pipeline (filter_search.hip).  Its result must
     be the oracle's, bit for bit, including ties, lists shorter than k and masses of duplicates (whole-group

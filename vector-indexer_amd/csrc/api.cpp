@@ -579,7 +579,7 @@ vi_status vi_indexer_last_build_stats(const vi_indexer *ix, vi_build_stats *out)
 }
 
 void vi_indexer_enable_timing(vi_indexer *ix, int enable) {
-  if (ix && ix->impl.dev) ix->impl.dev->timing = enable != 0;
+  if (ix && ix->impl.dev) ix->impl.dev->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
 }
 
 }  // extern "C"

@@ -135,7 +135,7 @@ struct DeviceIndex {
   mutable std::vector<SearchContext *> free_contexts;
   mutable vi_search_stats last_stats{};  // of the most recent search that finished on this handle
   SearchContext &cur() const;         // the context the calling thread holds (device_index_search acquired it)
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 HIP events at every phase boundary, 2 around the list-rank kernel only
 
   ~DeviceIndex();
 };

@@ -1186,7 +1186,7 @@ vi_status device_index_from_rows(int device, int order, uint32_t dim, const floa
 
 vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                  float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                                 bool timing, const uint32_t *probes_in, const uint32_t *order_in);
+                                 int timing_level, const uint32_t *probes_in, const uint32_t *order_in);
 vi_status coarse_only_filter(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint32_t P, hipStream_t st);
 bool filter_path_applicable(const DeviceIndex &ix, uint64_t nq, uint64_t k, uint32_t P);
 
@@ -1283,7 +1283,8 @@ vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uin
 
 vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t nq, uint64_t k, uint32_t P, uint32_t K,
                                float *Dd, int64_t *Id, uint64_t *Td, uint64_t *slots, uint32_t *counts, hipStream_t st,
-                               bool timing, const uint32_t *probes_in, const uint32_t *order_in) {
+                               int timing_level, const uint32_t *probes_in, const uint32_t *order_in) {
+  const bool timing = timing_level == 1, rank_timing = timing_level != 0;
   SearchWorkspace &ws = ix.cur().ws;
   vi_search_stats &stt = ix.cur().stats;
   const uint32_t dim = ix.dim, dq = ix.dq;
@@ -1329,7 +1330,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
   const uint64_t nsegruns = hstats[2];
   VI_TRY(ws.seg_run_dist.reserve(nsegruns * K));
   VI_TRY(ws.seg_run_pos.reserve(nsegruns * K));
-  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[2], st));
+  if (rank_timing) VI_HIP(hipEventRecord(ix.cur().ev[2], st));
   // ---- 4. list scan ----
   {
     ScanArgs a{};
@@ -1349,7 +1350,7 @@ vi_status search_valu_pipeline(const DeviceIndex &ix, const float *Qd, uint64_t 
       VI_HIP(hipGetLastError());
     }
   }
-  if (timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
+  if (rank_timing) VI_HIP(hipEventRecord(ix.cur().ev[3], st));
   // ---- 5. final merge ----
   {
     FinalMergeArgs a{ws.run_dist.p, ws.run_pos.p, (uint32_t)nq, P, K, (uint32_t)k, ws.probes.p, ws.gorder.p,
@@ -1430,7 +1431,7 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
   }
 
   const bool use_filter = !generic && filter_path_applicable(ix, nq, k, P);
-  const bool timing = ix.timing && !generic;
+  const int timing = generic ? 0 : ix.timing;
   if (io.probes_out) {  // coarse step only (multi-GPU: this rank's slice of the queries)
     if (P > kMaxSelect) VI_TRY(generic_probe_export(ix, Qd, nq, P, st));  // any n_probe: every coarse distance, sorted
     else if (filter_path_applicable(ix, nq, 1, P) && nq >= 256 && nlists >= 1024) VI_TRY(coarse_only_filter(ix, Qd, nq, P, st));
@@ -1472,10 +1473,10 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
     }
   }
   VI_HIP(hipStreamSynchronize(st));
-  if (timing) {
+  if (timing) (void)hipEventElapsedTime(&stt.ms_scan, ix.cur().ev[2], ix.cur().ev[3]);
+  if (timing == 1) {
     (void)hipEventElapsedTime(&stt.ms_coarse, ix.cur().ev[0], ix.cur().ev[1]);
     (void)hipEventElapsedTime(&stt.ms_group, ix.cur().ev[1], ix.cur().ev[2]);
-    (void)hipEventElapsedTime(&stt.ms_scan, ix.cur().ev[2], ix.cur().ev[3]);
     (void)hipEventElapsedTime(&stt.ms_merge, ix.cur().ev[3], ix.cur().ev[4]);
     (void)hipEventElapsedTime(&stt.ms_total, ix.cur().ev[0], ix.cur().ev[4]);
   }

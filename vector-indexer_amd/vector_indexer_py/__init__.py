@@ -103,7 +103,8 @@ class VectorIndex:
         return await loop.run_in_executor(None, self.search_sync, xq, k, n_probe)
 
     def enable_timing(self, on=True):
-        lib().vi_indexer_enable_timing(self._h, 1 if on else 0)
+        """True / 1: HIP events at every phase boundary; 2: around the list-rank kernel only (ms_scan); False / 0: none"""
+        lib().vi_indexer_enable_timing(self._h, 2 if on == 2 and on is not True else (1 if on else 0))
 
     def last_stats(self) -> dict:
         st = _native.SearchStats()
