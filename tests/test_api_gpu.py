@@ -223,6 +223,25 @@ def test_build_reports_its_phases(tmp_path):
     assert st["ms_total"] > 0 and abs(parts - st["ms_total"]) < 0.05 * st["ms_total"] + 1.0
 
 
+def test_timing_levels(tmp_path):
+    """vi_indexer_enable_timing: 0 no events, 1 one at every phase boundary, 2 around the list-rank kernel only (what
+    bench.py's timed region runs with); the results do not depend on it"""
+    rng = np.random.default_rng(11)
+    X = rng.integers(0, 200, size=(30000, 32)).astype(np.float32)
+    idx = vip.build(X, str(tmp_path), nlist=128)
+    Q = X[:600].copy()
+    ref = idx.search_sync(Q, 10, 8)
+    phases = ("ms_total", "ms_coarse", "ms_group", "ms_scan", "ms_merge")
+    st = idx.last_stats()
+    assert all(st[p] == 0 for p in phases)
+    for level, nonzero in ((True, set(phases)), (2, {"ms_scan"}), (False, set()), (1, set(phases))):
+        idx.enable_timing(level)
+        D, I = idx.search_sync(Q, 10, 8)
+        assert (I == ref[1]).all() and D.tobytes() == ref[0].tobytes()
+        st = idx.last_stats()
+        assert {p for p in phases if st[p] > 0} == nonzero, (level, {p: st[p] for p in phases})
+
+
 def test_concurrent_batches_of_different_shapes_on_one_handle(tmp_path):
     """8 threads (more than the 4 search contexts of a handle) issue batches of different sizes, k and n_probe — MFMA
     engine, coarse step on the matrix cores, generic path — at the same time; every result equals the one the same call
