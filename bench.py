@@ -266,9 +266,11 @@ def main():
                 probe_bufs[p_eff] = (po, pog, pa, oa)
             return probe_bufs[p_eff]
 
+    xq_p, D_p, I_p, T_p = xq.data_ptr(), D.data_ptr(), I.data_ptr(), T.data_ptr()
+
     def step(n_probe):
         if world == 1:
-            index.search_device(xq.data_ptr(), nq, k, n_probe, D.data_ptr(), I.data_ptr(), T.data_ptr())
+            index.search_device(xq_p, nq, k, n_probe, D_p, I_p, T_p)
             return I
         # The library works on its own blocking stream: it starts after what torch queued on the default stream
         # (incl. the wait for a collective) and returns when its own work is done — no explicit synchronisation here.
@@ -309,7 +311,7 @@ def main():
 
     def timed_step():
         step(head)
-        scan_ms.append(index.last_stats()["ms_scan"])
+        scan_ms.append(index.last_stat("ms_scan"))
     elapsed = time_steps(timed_step, args.steps, args.warmup, barrier, world, device)
     scan_ms = scan_ms[args.warmup:]
     st = index.last_stats()

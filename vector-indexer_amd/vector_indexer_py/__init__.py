@@ -111,6 +111,14 @@ class VectorIndex:
         _native.check(lib().vi_indexer_last_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def last_stat(self, field: str):
+        """one field of last_stats() without building the dict (a timed loop reads ms_scan after every step)"""
+        st = self.__dict__.get("_stat_buf")
+        if st is None:
+            st = self.__dict__["_stat_buf"] = _native.SearchStats()
+        _native.check(lib().vi_indexer_last_stats(self._h, C.byref(st)))
+        return getattr(st, field)
+
     def build_stats(self) -> dict:
         st = _native.BuildStats()
         _native.check(lib().vi_indexer_last_build_stats(self._h, C.byref(st)))
