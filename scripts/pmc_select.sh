@@ -12,7 +12,7 @@ G[a]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 G[b]="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM"
 G[c]="TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
 G[d]="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum SQ_IFETCH_LEVEL SQC_ICACHE_MISSES SQC_ICACHE_REQ SQ_INSTS_BRANCH SQ_WAVES"
-for g in a b c d; do
+for g in ${GROUPS_TO_RUN:-a b}; do   # (c d: TA / TCP / instruction-cache counters — a pass takes ~3 minutes: the index build runs under the counters too)
   rm -rf $R/gpurun_out/pmc_${TAG}_$g
   rocprofv3 --pmc ${G[$g]} --output-format csv -d $R/gpurun_out/pmc_${TAG}_$g -- $CMD > $R/gpurun_out/pmc_${TAG}_$g.log 2>&1 || { echo "pass $g failed"; tail -5 $R/gpurun_out/pmc_${TAG}_$g.log; }
 done
