@@ -1028,6 +1028,14 @@ __device__ __forceinline__ vf2 pk_sub_f32(vf2 a, vf2 b) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// acc += (q - x)^2 over four consecutive dimensions in the reference's order: differences and squares two at a time
+// (packed instructions: each component rounds exactly as the scalar instruction does), the sum one term after the other
+__device__ __forceinline__ void sq_add4(float &acc, const float4 &q, const float4 &x) {
+  const vf2 qa = {q.x, q.y}, qb = {q.z, q.w}, xa = {x.x, x.y}, xb = {x.z, x.w};
+  const vf2 ta = pk_sub_f32(qa, xa), tb = pk_sub_f32(qb, xb);
+  const vf2 sa = ta * ta, sb = tb * tb;
+  acc = acc + sa.x; acc = acc + sa.y; acc = acc + sb.x; acc = acc + sb.y;
+}
 #define VI_AS_LDS __attribute__((address_space(3)))
 #define VI_AS_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ float4 lds_f4(const float *p) {
@@ -1061,13 +1069,13 @@ __device__ __forceinline__ float exact_pair(const float *qrow, const float4 *xv,
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 qq = lds_f4(qrow + 4 * (qd + i));
-      sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
+      sq_add4(acc, qq, x[i]);
     }
   }
   for (; qd < nquad; ++qd) {
     const float4 qq = lds_f4(qrow + 4 * qd);
     const float4 xx = glb_f4(xv + (size_t)qd * kWave);
-    sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
+    sq_add4(acc, qq, xx);
   }
   return acc;
 }
@@ -1084,13 +1092,13 @@ __device__ __forceinline__ float exact_pair_row(const float *qrow, const float4 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 qq = lds_f4(qrow + 4 * (qd + i));
-      sq_add(acc, qq.x, x[i].x); sq_add(acc, qq.y, x[i].y); sq_add(acc, qq.z, x[i].z); sq_add(acc, qq.w, x[i].w);
+      sq_add4(acc, qq, x[i]);
     }
   }
   for (; qd < nquad; ++qd) {
     const float4 qq = lds_f4(qrow + 4 * qd);
     const float4 xx = glb_f4(xr + qd);
-    sq_add(acc, qq.x, xx.x); sq_add(acc, qq.y, xx.y); sq_add(acc, qq.z, xx.z); sq_add(acc, qq.w, xx.w);
+    sq_add4(acc, qq, xx);
   }
   return acc;
 }
