@@ -1110,12 +1110,12 @@ __device__ __forceinline__ float exact_pair_bf16(const float *qrow, const uint4 
   const uint32_t npiece = (dim + 7u) >> 3;  // (dim % 4 == 0: the last piece may hold 4 dimensions)
   auto piece = [&](const uint4 &x, uint32_t p) {
     const float4 q0 = lds_f4(qrow + 8 * p);
-    sq_add(acc, q0.x, __uint_as_float(x.x << 16)); sq_add(acc, q0.y, __uint_as_float(x.x & 0xFFFF0000u));
-    sq_add(acc, q0.z, __uint_as_float(x.y << 16)); sq_add(acc, q0.w, __uint_as_float(x.y & 0xFFFF0000u));
+    sq_add4(acc, q0, make_float4(__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xFFFF0000u), __uint_as_float(x.y << 16),
+                                 __uint_as_float(x.y & 0xFFFF0000u)));
     if (8 * p + 4 < dim) {
       const float4 q1 = lds_f4(qrow + 8 * p + 4);
-      sq_add(acc, q1.x, __uint_as_float(x.z << 16)); sq_add(acc, q1.y, __uint_as_float(x.z & 0xFFFF0000u));
-      sq_add(acc, q1.z, __uint_as_float(x.w << 16)); sq_add(acc, q1.w, __uint_as_float(x.w & 0xFFFF0000u));
+      sq_add4(acc, q1, make_float4(__uint_as_float(x.z << 16), __uint_as_float(x.z & 0xFFFF0000u), __uint_as_float(x.w << 16),
+                                   __uint_as_float(x.w & 0xFFFF0000u)));
     }
   };
   uint32_t p = 0;
@@ -1143,8 +1143,7 @@ __device__ __forceinline__ float exact_pair_u8(const float *qrow, const uint4 *x
   const uint32_t npiece = (dim + 15u) >> 4;  // (dim % 4 == 0: the last piece may hold 4, 8 or 12 dimensions)
   auto word = [&](uint32_t w, uint32_t e) {   // 4 dimensions starting at e
     const float4 q = lds_f4(qrow + e);
-    sq_add(acc, q.x, (float)(w & 0xFFu)); sq_add(acc, q.y, (float)((w >> 8) & 0xFFu));
-    sq_add(acc, q.z, (float)((w >> 16) & 0xFFu)); sq_add(acc, q.w, (float)(w >> 24));
+    sq_add4(acc, q, make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24)));
   };
   auto piece = [&](const uint4 &x, uint32_t p) {
     const uint32_t e = 16 * p;
