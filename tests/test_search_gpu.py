@@ -633,3 +633,46 @@ def test_real_valued_lists_far_from_the_origin(d, n, nlist, approx, centre, tmp_
         elif approx in ("1", "2"):
             assert mode in (4, 6), mode
     check_parity(orc, gpu, Q[:7], 10, 8)
+
+
+@pytest.mark.parametrize("placement", [0, 1])
+def test_ranks_with_real_valued_lists_far_from_the_origin(placement, tmp_path):
+    """Stripes / shard placement with real-valued lists about a common offset: every rank takes its ranking images about
+    the mean of ITS resident vectors (rank_mode 5 / 6) — the centres differ from rank to rank, the merged result is the
+    oracle's all the same (only exact distances and tie keys leave a rank)."""
+    if os.environ.get("VI_FILTER") == "0" or os.environ.get("VI_FILTER_BF16") == "0":
+        pytest.skip("centred images belong to the bf16 MFMA engine")
+    from vector_indexer_py import _native
+    world, d, n = 3, 48, 30000
+    rng = np.random.default_rng(23)
+    centers = (-250.0 + 8.0 * rng.standard_normal((40, d))).astype(np.float32)
+    X = (centers[rng.integers(0, 40, n)] + rng.standard_normal((n, d)).astype(np.float32) * 2.0).astype(np.float32)
+    orc, full = oracle_and_gpu(tmp_path, X, nlist=1100)
+    Q = np.ascontiguousarray(np.concatenate([(centers[rng.integers(0, 40, 400)] + rng.standard_normal((400, d)).astype(np.float32) * 2.0)
+                                             .astype(np.float32), X[:50], np.zeros((2, d), np.float32)]))
+    idx, sh = str(tmp_path / "index"), str(tmp_path / "shards")
+    parts = [vip.load(idx, sh, d, rank=r, world_size=world, placement=placement) for r in range(world)]
+    hip = _Hip()
+    try:
+        nq = Q.shape[0]
+        xq = hip.upload(Q)
+        for k, n_probe in [(10, 16), (64, 40), (1, 1)]:
+            Dg, Ig, Tg = hip.alloc(world * nq * k * 4), hip.alloc(world * nq * k * 8), hip.alloc(world * nq * k * 8)
+            p_eff = min(n_probe, full.num_centroids)
+            probes, order = hip.alloc(nq * p_eff * 4), hip.alloc(nq * p_eff * 4)
+            per = (nq + world - 1) // world
+            for r, p in enumerate(parts):   # the coarse step split over the ranks by query (each on ITS centred table)
+                q0, q1 = min(nq, r * per), min(nq, (r + 1) * per)
+                if q1 > q0:
+                    assert p.probe_device(xq + q0 * d * 4, q1 - q0, n_probe, probes + q0 * p_eff * 4, order + q0 * p_eff * 4) == p_eff
+            for r, p in enumerate(parts):
+                p.search_probed_device(xq, nq, k, p_eff, probes, order, Dg + r * nq * k * 4, Ig + r * nq * k * 8, Tg + r * nq * k * 8)
+                assert p.last_stats()["rank_mode"] in (5, 6), p.last_stats()["rank_mode"]
+            Dm, Im = hip.alloc(nq * k * 4), hip.alloc(nq * k * 8)
+            _native.check(_native.lib().vi_merge_partials_device(0, nq, k, world, Dg, Ig, Tg, Dm, Im))
+            rc, Do, Io = orc.search_batch(Q, k, n_probe)
+            assert rc == O.ORC_OK
+            assert (hip.download(Im, (nq, k), np.int64) == Io).all(), (k, n_probe)
+            assert (bits(hip.download(Dm, (nq, k), np.float32)) == bits(Do)).all(), (k, n_probe)
+    finally:
+        hip.close()
