@@ -1921,18 +1921,23 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
     incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
     const uint32_t total = readlane_u(incl, 63);
     if (total <= kPickCap) {
-      uint32_t at = incl - mine;
+      uint32_t at = incl - mine, left = cls;
+      // (a lane flags 0.7 of its 8 sub-blocks on average: as many rounds as the busiest lane has flags — three or four —
+      //  each lane taking its next flagged sub-block, instead of eight rounds of mostly idle lanes)
+      while (__ballot(left != 0u)) {
+        if (left != 0u) {
+          const uint32_t sb = (uint32_t)__builtin_ctz(left) >> 1;
+          const uint32_t k = (left >> (2u * sb)) & 3u, rec = (sb >> 1) * kWave + (uint32_t)lane;
+          left &= ~(3u << (2u * sb));
+          if (k == 1u) {
+            pick[at] = sub_row(rec, sb & 1u, (rowbits >> (3u * sb)) & 7u);
+            at += 1u;
+          } else {
 #pragma unroll
-      for (uint32_t sb = 0; sb < 2u * kPer; ++sb) {
-        const uint32_t k = (cls >> (2u * sb)) & 3u, rec = (sb >> 1) * kWave + lane;
-        if (k == 1u) {
-          pick[at] = sub_row(rec, sb & 1u, (rowbits >> (3u * sb)) & 7u);
-          at += 1u;
-        } else if (k == 2u) {
-#pragma unroll
-          for (uint32_t e = 0; e < 8u; ++e) pick[at + e] = sub_row(rec, sb & 1u, e);
-          at += 8u;
-          n_whole += 1u;  // (per lane here; summed below when the counters are on)
+            for (uint32_t e = 0; e < 8u; ++e) pick[at + e] = sub_row(rec, sb & 1u, e);
+            at += 8u;
+            n_whole += 1u;  // (per lane here; summed below when the counters are on)
+          }
         }
       }
       npick = total;
