@@ -57,6 +57,11 @@ __global__ void topk_kernel(const float *d, const uint32_t *p, int rounds, int K
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
 
+__global__ void scan_kernel(const uint32_t *in, uint32_t *out) {  // one wave per 64 values
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  out[i] = wave_incl_scan_u32(in[i]);
+}
+
 static uint32_t sortable_host(float x) {
   uint32_t b; memcpy(&b, &x, 4);
   if (x != x) return 0xFFFFFFFFu;
@@ -65,6 +70,28 @@ static uint32_t sortable_host(float x) {
 
 int main() {
   int bad = 0;
+  {  // inclusive scan over the lanes
+    const int rows = 512;
+    std::vector<uint32_t> h(rows * 64), g(rows * 64);
+    std::mt19937 r2(5);
+    for (auto &v : h) v = r2() % 3 == 0 ? 0u : r2() % 1000u;
+    for (int l = 0; l < 64; ++l) { h[l] = 1u; h[64 + l] = (uint32_t)l; }   // all ones; the lane index
+    uint32_t *di, *dout; CK(hipMalloc(&di, h.size() * 4)); CK(hipMalloc(&dout, h.size() * 4));
+    CK(hipMemcpy(di, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scan_kernel, dim3(rows), dim3(64), 0, 0, di, dout);
+    CK(hipMemcpy(g.data(), dout, g.size() * 4, hipMemcpyDeviceToHost));
+    int b0 = 0;
+    for (int w = 0; w < rows; ++w) {
+      uint32_t run = 0;
+      for (int l = 0; l < 64; ++l) {
+        run += h[w * 64 + l];
+        if (g[w * 64 + l] != run) { if (b0 < 5) printf("scan row %d lane %d: got %u want %u\n", w, l, g[w * 64 + l], run); ++b0; }
+      }
+    }
+    printf("scan: %d wrong prefix sums\n", b0);
+    bad += b0;
+    CK(hipFree(di)); CK(hipFree(dout));
+  }
   {  // exchanges
     uint32_t *d; CK(hipMalloc(&d, 11 * 64 * 4));
     hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(64), 0, 0, d);

@@ -1767,12 +1767,7 @@ __global__ void __launch_bounds__(256, 4) coarse_select_kernel(CoarseSelectArgs 
     uint32_t sb;
     ng = 2u * list_segments(a.list_len[mylist], a.list_segb0, &sb);
   }
-  uint32_t ig = ng;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t x = (uint32_t)__shfl_up((int)ig, o);
-    if (lane >= o) ig += x;
-  }
+  const uint32_t ig = wave_incl_scan_u32(ng);
   if ((uint32_t)lane < a.P) a.rel[(size_t)q * a.P + lane] = ig - ng;
   if (lane == 63) a.qtot[q] = ig;
 }
@@ -1912,13 +1907,7 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
           mine += all8 ? 8u : (cand ? 1u : 0u);
         }
       }
-    uint32_t incl = mine;  // inclusive scan over the lanes (DPP: shifts within rows of 16, then the row totals)
-    incl += dpp_u32<0x111>(0u, incl);  // row_shr:1
-    incl += dpp_u32<0x112>(0u, incl);  // row_shr:2
-    incl += dpp_u32<0x114>(0u, incl);  // row_shr:4
-    incl += dpp_u32<0x118>(0u, incl);  // row_shr:8
-    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
-    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+    const uint32_t incl = wave_incl_scan_u32(mine);
     const uint32_t total = readlane_u(incl, 63);
     if (total <= kPickCap) {
       uint32_t at = incl - mine, left = cls;
@@ -2007,12 +1996,7 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
     uint32_t sb;
     ng = 2u * list_segments(a.list_len[mylist], a.list_segb0, &sb);
   }
-  uint32_t ig = ng;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t x = (uint32_t)__shfl_up((int)ig, o);
-    if (lane >= o) ig += x;
-  }
+  const uint32_t ig = wave_incl_scan_u32(ng);
   if ((uint32_t)lane < a.P) a.rel[(size_t)q * a.P + lane] = ig - ng;
   if (lane == 63) a.qtot[q] = ig;
   lap(4);

@@ -64,6 +64,18 @@ __device__ __forceinline__ uint64_t exchange_u64(uint64_t k, int lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// inclusive prefix sum over the 64 lanes: shifts within the rows of 16 lanes, then the row totals (row_bcast) — six DPP
+// adds, no LDS crossbar (a __shfl_up loop is six dependent ds_bpermute round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+  x += dpp_u32<0x111>(0u, x);  // row_shr:1  (lanes without a source take the `old` operand: 0)
+  x += dpp_u32<0x112>(0u, x);  // row_shr:2
+  x += dpp_u32<0x114>(0u, x);  // row_shr:4
+  x += dpp_u32<0x118>(0u, x);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2, 3
+  return x;
+}
+
 // compare-exchange with the partner lane: the lane whose `keep_min` is set keeps the smaller key
 template <Ex E>
 __device__ __forceinline__ void cmpx_u64(uint64_t &k, int lane, bool keep_min) {
