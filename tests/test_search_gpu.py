@@ -366,6 +366,38 @@ def test_randomized_shapes_parity(seed, tmp_path):
         check_parity(orc, gpu, Q, k, n_probe)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VI_FUZZ_SEEDS_TABLE", "6"))))
+def test_randomized_large_tables_parity(seed, tmp_path):
+    """the same with >= 1024 lists and >= 256 queries, where the coarse step runs on the matrix cores too (centroid table as
+    one list, direct coarse select: row lists, whole-wave row fetch for D % 16 == 0, a row per lane otherwise)"""
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([16, 20, 32, 48, 64, 96, 100, 128, 8]))
+    nlist = int(rng.integers(1024, 2600))
+    n = int(nlist * rng.integers(6, 24))
+    kind = rng.choice(["gauss", "ints", "clustered", "offset", "scaled"])
+    if kind == "gauss":
+        X = rng.standard_normal((n, d))
+    elif kind == "ints":
+        X = rng.integers(0, 256, size=(n, d))
+    elif kind == "clustered":
+        cen = rng.standard_normal((64, d)) * 6
+        X = cen[rng.integers(0, 64, n)] + rng.standard_normal((n, d))
+    elif kind == "offset":
+        X = float(rng.choice([-80.0, 40.0, 300.0])) + rng.standard_normal((n, d)) * float(rng.choice([0.5, 3.0]))
+    else:
+        X = rng.standard_normal((n, d)) * np.exp(rng.uniform(-3, 3, size=(1, d)))
+    X = X.astype(np.float32)
+    orc, gpu = oracle_and_gpu(tmp_path, X, nlist=nlist)
+    nq = int(rng.choice([256, 300, 513, 900]))
+    Q = np.concatenate([X[rng.integers(0, n, size=nq // 2)],
+                        (X[rng.integers(0, n, size=nq)] * (1 + 0.05 * rng.standard_normal((nq, d)))).astype(np.float32)])[:nq]
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    for _ in range(3):
+        k = int(rng.choice([1, 10, 33, 64, 100]))
+        n_probe = int(rng.choice([1, 8, 32, 64]))
+        check_parity(orc, gpu, Q, k, n_probe)
+
+
 def test_any_u64_is_a_legal_external_id(tmp_path):
     """external ids are arbitrary u64 (api.rs:57-62; shards_tests.rs:412-456 uses huge ids): 2^64-1, 2^63 and 0 are
     ordinary vectors under every engine — pad slots are told from the list layout, never from the stored id"""
