@@ -64,6 +64,8 @@ struct SearchWorkspace {
   DevBuf<uint32_t> c_seg, c_item, c_pairs;  // the coarse table grouped as one list ...
   uint64_t c_nq = 0;                        // ... for this batch size
   DevBuf<uint32_t> pair_rel, qtot, qoff;    // group-record offsets: per (query, probe), per query, scan over queries
+  DevBuf<uint32_t> pair_rank;               // a pair's place among the pairs of its (list, sub-bin): from the direct coarse select
+  bool pair_rank_valid = false;             // ... filled by this search
   DevBuf<uint32_t> item_list;               // list of each rank work item
   DevBuf<uint32_t> items;                   // ... or its whole descriptor (8 words), item_desc_kernel
   DevBuf<uint64_t> prof;                    // diagnostic counters (VI_STREAM_PROF)

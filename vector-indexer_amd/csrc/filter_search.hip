@@ -59,7 +59,7 @@ vi_status adopt_probes(const DeviceIndex &ix, uint64_t nq, uint32_t P, const uin
                        bool histogram, hipStream_t st);
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot = nullptr,
-                          uint32_t *qoff = nullptr);
+                          uint32_t *qoff = nullptr, const uint32_t *pair_rank = nullptr);
 bool grouping_fuses_query_offsets(const DeviceIndex &ix);
 
 namespace {
@@ -1733,6 +1733,8 @@ struct CoarseSelectArgs {
   uint32_t list_segb0;
   uint32_t *rel, *qtot;
   uint32_t staged;  // single rows fetched by the whole wave through LDS (exact_batch_rows_staged_fn); VI_COARSE_STAGED=0: a row per lane
+  uint32_t *pair_rank;  // direct kernel: where the pair stands among the pairs of its (list, sub-bin) — the value its histogram
+                        // increment returns — so that the grouping's scatter needs no atomics of its own; or null
 };
 
 // one wave per query: the P nearest centroids in (distance, centroid index) order (the reference's stable
@@ -1989,7 +1991,10 @@ __global__ void __launch_bounds__(256) coarse_select_direct_kernel(CoarseSelectA
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
-    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
+    if (mylist != kNoPos && a.list_len[mylist] > 0) {
+      const uint32_t before = atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
+      if (a.pair_rank) a.pair_rank[(size_t)q * a.P + lane] = before;
+    }
   }
   uint32_t ng = 0;
   if (mylist != kNoPos) {
@@ -2419,6 +2424,11 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
                        ws.cnt.p, qmajor ? 1u : 0u, nullptr, list_segb0, ws.pair_rel.p, ws.qtot.p};
     { const char *e = getenv("VI_COARSE_ROWS"); if (ix.cent_rows.p && !(e && *e == '0')) a.cent_rows = (const float4 *)ix.cent_rows.p; }
     { const char *e = getenv("VI_COARSE_STAGED"); a.staged = (e && *e == '0') || (ix.dim & 15u) ? 0u : 1u; }
+    {
+      const char *e = getenv("VI_SCATTER_RANKED");
+      ws.pair_rank_valid = direct && !(e && *e == '0');
+      if (ws.pair_rank_valid) { VI_TRY(ws.pair_rank.reserve(nq * P)); a.pair_rank = ws.pair_rank.p; }
+    }
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
     { const char *e = getenv("VI_SELECT_XMODE_COARSE"); a.c.xmode = e ? (uint32_t)atoi(e) : 0u; }
     if (direct) a.c.e_scale += (float)(1.01 * std::ldexp(1.0, -20));  // the row index rides in 3 mantissa bits of the minima
@@ -2498,6 +2508,7 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     VI_HIP(hipMemsetAsync(ws.stats.p + 6, 0, 6 * sizeof(uint64_t), st));
     VI_HIP(hipMemsetAsync(ws.stats.p + 150, 0, 8 * sizeof(uint64_t), st));
   }
+  ws.pair_rank_valid = false;  // (set by the direct coarse select of THIS search)
   if (timing) VI_HIP(hipEventRecord(ix.cur().ev[0], st));
   // the batch's queries as MFMA operands: -2 q split into bf16 hi / lo once (a query sits in n_probe work items)
   const char *cf = getenv("VI_COARSE_FILTER");
@@ -2557,7 +2568,8 @@ vi_status search_filter_pipeline(const DeviceIndex &ix, const float *Qd, uint64_
     gq = e && atoi(e) == 256 && ws.queries_hi_only ? 256u : 128u;
   }
   const bool fuse_q = grouping_fuses_query_offsets(ix);
-  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true, fuse_q ? ws.qtot.p : nullptr, fuse_q ? ws.qoff.p : nullptr));
+  VI_TRY(launch_grouping(ix, ws.probes.p, nq, P, (int)gq, segb0, hstats, st, true, fuse_q ? ws.qtot.p : nullptr, fuse_q ? ws.qoff.p : nullptr,
+                         ws.pair_rank_valid ? ws.pair_rank.p : nullptr));
   {
     const double fill128 = hstats[12] ? (double)hstats[0] / ((double)hstats[12] * 128.0 * 64.0) : 0.0;
     const uint32_t next = fill128 >= 0.3 ? 128u : 32u;

@@ -230,7 +230,7 @@ vi_status sort_rows_u64(uint64_t *keys, uint64_t nrows, uint32_t logL, hipStream
 // declared in search_kernels.hip
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
                           uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot = nullptr,
-                          uint32_t *qoff = nullptr);
+                          uint32_t *qoff = nullptr, const uint32_t *pair_rank = nullptr);
 bool grouping_fuses_query_offsets(const DeviceIndex &ix);
 
 // declared in search_kernels.hip

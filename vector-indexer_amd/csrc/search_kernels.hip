@@ -594,6 +594,21 @@ __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *lis
   if (pair_pos) pair_pos[i] = pos - seg_start[l];  // MFMA path: where the pair sits among the pairs of its list
 }
 
+// the same without atomics: the pair's place among the pairs of its (list, sub-bin) came back from the histogram
+// increment of the kernel that chose the probe (coarse_select_direct_kernel) — 320 000 returning atomics on counters
+// shared across the XCDs were most of the scatter's 17 us
+__global__ void group_scatter_ranked_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t P,
+                                            const uint32_t *cursor, const uint32_t *pair_rank, uint32_t *pairs, uint32_t total,
+                                            const uint32_t *seg_start, uint32_t *pair_pos) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t l = probes[i];
+  if (l >= nlists || list_len[l] == 0) return;
+  const uint32_t pos = cursor[subbin_index(l, (i / P) & (kSubBins - 1), nlists)] + pair_rank[i];
+  pairs[pos] = i;
+  if (pair_pos) pair_pos[i] = pos - seg_start[l];
+}
+
 // caller-supplied probe lists (multi-GPU: another rank's coarse step): every probe must name a list of this index or be the
 // empty marker, the real probes of a row must come first, and the candidate-order ranks must be a rank < P or the marker
 __global__ void validate_probes_kernel(const uint32_t *probes, const uint32_t *order, uint32_t total, uint32_t P,
@@ -1488,7 +1503,8 @@ vi_status device_index_search(const DeviceIndex &ix, const SearchIO &io) {
 bool grouping_fuses_query_offsets(const DeviceIndex &) { return true; }
 
 vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_t nq, uint32_t P, int qg, uint32_t segb0,
-                          uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot, uint32_t *qoff) {
+                          uint64_t hstats[14], hipStream_t st, bool histogram_done, const uint32_t *qtot, uint32_t *qoff,
+                          const uint32_t *pair_rank) {
   SearchWorkspace &ws = ix.cur().ws;
   const uint64_t nlists = ix.nlists;
   const uint32_t total = (uint32_t)(nq * P);
@@ -1513,8 +1529,12 @@ vi_status launch_grouping(const DeviceIndex &ix, const uint32_t *probes, uint64_
   if (!ws.hstats_pinned) VI_HIP(hipHostMalloc((void **)&ws.hstats_pinned, 16 * sizeof(uint64_t)));
   VI_HIP(hipMemcpyAsync(ws.hstats_pinned, ws.stats.p, 14 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   VI_HIP(hipEventRecord(ix.cur().ev[5], st));
-  hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
-                     (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
+  if (pair_rank && histogram_done)
+    hipLaunchKernelGGL(group_scatter_ranked_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
+                       (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), pair_rank, ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
+  else
+    hipLaunchKernelGGL(group_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, probes, ix.list_len.p,
+                       (uint32_t)nlists, P, ws.cnt.p + subbin_words(nlists), ws.pairs.p, total, ws.seg_start.p, ws.pair_pos.p);
   VI_HIP(hipGetLastError());
   VI_HIP(hipEventSynchronize(ix.cur().ev[5]));
   std::memcpy(hstats, ws.hstats_pinned, 14 * sizeof(uint64_t));
