@@ -409,7 +409,7 @@ __global__ void item_cols_kernel(const uint4 *items, const uint32_t *pairs, cons
     uint32_t q = ~0u, g = ~0u;
     if (col < d0.y) {
       const uint32_t slot = pairs[d0.x + col];
-      q = slot / P;
+      q = div_probes(slot, P);
       g = qoff[q] + rel[slot] + 2u * d1.y;
       const uint32_t place = (slot - q * P) | (d1.y << 6);
       *reinterpret_cast<uint2 *>(gmeta + g) = make_uint2(place, place | (1u << 13));  // (g is even: 8-byte aligned)

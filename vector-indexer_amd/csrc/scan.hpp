@@ -58,7 +58,22 @@ __host__ __device__ inline uint32_t list_segments(uint32_t len, uint32_t segb0, 
   uint32_t sb = (nblk + 63) / 64;
   if (sb < segb0) sb = segb0;
   *segb = sb;
+  // (sb is the configured segment size — a power of two — for every list below 64 * segb0 blocks: a shift; a 32-bit division
+  //  by a run-time value is ~35 instructions on this GPU, and this sits in the per-probe code of both select kernels)
+  if ((sb & (sb - 1u)) == 0u) return (nblk + sb - 1u) >> (uint32_t)__builtin_ctz(sb);
   return nblk == 0 ? 0u : (nblk + sb - 1) / sb;
+}
+
+// i / P for a probe count that is a power of two more often than not
+__host__ __device__ inline uint32_t div_probes(uint32_t i, uint32_t P) {
+  if ((P & (P - 1u)) == 0u) return i >> (uint32_t)__builtin_ctz(P);
+  return i / P;
+}
+
+// ceil(c / qg) for a group width that is a power of two in practice (32 / 128 / 256)
+__host__ __device__ inline uint32_t group_chunks(uint32_t c, uint32_t qg) {
+  if ((qg & (qg - 1u)) == 0u) return (c + qg - 1u) >> (uint32_t)__builtin_ctz(qg);
+  return (c + qg - 1u) / qg;
 }
 
 // pair records one list segment of segb blocks reserves per query group (every segment of a list reserves the same

@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     const uint32_t len = list_len[l];
     uint32_t segb;
     const uint32_t ns = list_segments(len, segb0, &segb);
-    const uint32_t chunks = (c + qg - 1) / qg;
+    const uint32_t chunks = group_chunks(c, qg);
     seg += c;
     item += chunks * ns;
     run += ns > 1 ? c * ns : 0u;
@@ -458,8 +458,8 @@ __global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, c
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
     if (tile_start) tile_start[l] = rt;
     const uint32_t c = cnt[l];
-    rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += ((c + qg - 1) / qg) * ns * seg_records(segb);
+    rs += c; ri += (group_chunks(c, qg)) * ns; rr += ns > 1 ? c * ns : 0u;
+    rt += (group_chunks(c, qg)) * ns * seg_records(segb);
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt
     const uint32_t len = list_len[l];
     uint32_t segb;
     const uint32_t ns = list_segments(len, segb0, &segb);
-    const uint32_t chunks = (c + qg - 1) / qg;
+    const uint32_t chunks = group_chunks(c, qg);
     seg += c;
     item += chunks * ns;
     run += ns > 1 ? c * ns : 0u;
@@ -559,8 +559,8 @@ __global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt
     seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
     if (tile_start) tile_start[l] = rt;
     const uint32_t c = cnt[l];
-    rs += c; ri += ((c + qg - 1) / qg) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += ((c + qg - 1) / qg) * ns * seg_records(segb);
+    rs += c; ri += (group_chunks(c, qg)) * ns; rr += ns > 1 ? c * ns : 0u;
+    rt += (group_chunks(c, qg)) * ns * seg_records(segb);
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
@@ -579,7 +579,7 @@ __global__ void histogram_kernel(const uint32_t *probes, const uint32_t *list_le
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t l = probes[i];
-  if (l < nlists && list_len[l] > 0) atomicAdd(&cnt[subbin_index(l, (i / P) & (kSubBins - 1), nlists)], 1u);
+  if (l < nlists && list_len[l] > 0) atomicAdd(&cnt[subbin_index(l, div_probes(i, P) & (kSubBins - 1), nlists)], 1u);
 }
 
 __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *list_len, uint32_t nlists, uint32_t P,
@@ -589,7 +589,7 @@ __global__ void group_scatter_kernel(const uint32_t *probes, const uint32_t *lis
   if (i >= total) return;
   const uint32_t l = probes[i];
   if (l >= nlists || list_len[l] == 0) return;
-  const uint32_t pos = atomicAdd(&cursor[subbin_index(l, (i / P) & (kSubBins - 1), nlists)], 1u);
+  const uint32_t pos = atomicAdd(&cursor[subbin_index(l, div_probes(i, P) & (kSubBins - 1), nlists)], 1u);
   pairs[pos] = i;  // slot id = q*P + rank
   if (pair_pos) pair_pos[i] = pos - seg_start[l];  // MFMA path: where the pair sits among the pairs of its list
 }
@@ -604,7 +604,7 @@ __global__ void group_scatter_ranked_kernel(const uint32_t *probes, const uint32
   if (i >= total) return;
   const uint32_t l = probes[i];
   if (l >= nlists || list_len[l] == 0) return;
-  const uint32_t pos = cursor[subbin_index(l, (i / P) & (kSubBins - 1), nlists)] + pair_rank[i];
+  const uint32_t pos = cursor[subbin_index(l, div_probes(i, P) & (kSubBins - 1), nlists)] + pair_rank[i];
   pairs[pos] = i;
   if (pair_pos) pair_pos[i] = pos - seg_start[l];
 }
