@@ -32,6 +32,7 @@
 #include "device_math.hpp"
 #include "scan.hpp"
 #include "wave_select.hpp"
+#include "wave_sort.hpp"
 
 namespace vi {
 namespace {
@@ -506,61 +507,84 @@ __global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt
     return;
   }
   // ---- lists (cnt = the per-list totals of list_totals_kernel, which also reset the counters added to below) ----
-  const uint32_t per = (nlists + 1023) / 1024;
-  const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
-  uint32_t seg = 0, item = 0, run = 0, tile = 0;
-  unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
-  for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = cnt[l];
-    const uint32_t len = list_len[l];
+  // Wave w owns the contiguous lists [w R 64, (w + 1) R 64) as R rows of 64, a lane per list: every load and store is one
+  // coalesced instruction, eight rows' loads in flight together.  (A thread walking its own 64 lists — 65 536 lists — read
+  // and wrote with a stride of 256 bytes between lanes, 64 cache lines per instruction, all from the one CU this scan runs
+  // on: 0.34 ms of a 4.9 ms search.)  Pass 1: the wave's totals; pass 2, behind the workgroup's prefix over the waves: a
+  // DPP scan per row and quantity, the carry from row to row.
+  const uint32_t rows = ((nlists + 63u) / 64u + 15u) / 16u;  // rows of 64 lists per wave
+  const uint32_t l_base = (uint32_t)wave * rows * 64u;
+  struct PerList { uint32_t seg, item, run, tile; };
+  auto per_list = [&](uint32_t c, uint32_t len, unsigned long long *v4) {
     uint32_t segb;
     const uint32_t ns = list_segments(len, segb0, &segb);
     const uint32_t chunks = group_chunks(c, qg);
-    seg += c;
-    item += chunks * ns;
-    run += ns > 1 ? c * ns : 0u;
-    vec += (unsigned long long)c * len;
-    mtile += (unsigned long long)chunks * ((len + 63) / 64);
-    mtile128 += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);
-    tile += chunks * ns * seg_records(segb);
-    rec += 2ull * c * ns;
-  }
-  uint32_t iseg = seg, iitem = item, irun = run, itile = tile;
+    if (v4) {
+      v4[0] += (unsigned long long)c * len;
+      v4[1] += 2ull * c * ns;
+      v4[2] += (unsigned long long)chunks * ((len + 63) / 64);
+      v4[3] += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);
+    }
+    return PerList{c, chunks * ns, ns > 1 ? c * ns : 0u, chunks * ns * seg_records(segb)};
+  };
+  uint32_t seg = 0, item = 0, run = 0, tile = 0;  // this lane's column sums over the wave's rows
+  unsigned long long v4[4] = {0, 0, 0, 0};        // vec, rec, mtile, mtile128
+  for (uint32_t r0 = 0; r0 < rows; r0 += 8) {
+    uint32_t cs[8], lens[8];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t a = (uint32_t)__shfl_up((int)iseg, o), b = (uint32_t)__shfl_up((int)iitem, o);
-    const uint32_t r = (uint32_t)__shfl_up((int)irun, o), tt = (uint32_t)__shfl_up((int)itile, o);
-    if (lane >= o) { iseg += a; iitem += b; irun += r; itile += tt; }
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t l = l_base + (r0 + u) * 64u + (uint32_t)lane;
+      const bool in = r0 + u < rows && l < nlists;
+      cs[u] = in ? cnt[l] : 0u;
+      lens[u] = in ? list_len[l] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const PerList p = per_list(cs[u], lens[u], v4);  // (rows past the end: zeros)
+      seg += p.seg; item += p.item; run += p.run; tile += p.tile;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    vec += __shfl_xor(vec, o);
-    rec += __shfl_xor(rec, o);
-    mtile += __shfl_xor(mtile, o);
-    mtile128 += __shfl_xor(mtile128, o);
+    seg += (uint32_t)__shfl_xor((int)seg, o); item += (uint32_t)__shfl_xor((int)item, o);
+    run += (uint32_t)__shfl_xor((int)run, o); tile += (uint32_t)__shfl_xor((int)tile, o);
+    v4[0] += __shfl_xor(v4[0], o); v4[1] += __shfl_xor(v4[1], o); v4[2] += __shfl_xor(v4[2], o); v4[3] += __shfl_xor(v4[3], o);
   }
-  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
   if (lane == 0) {
-    atomicAdd((unsigned long long *)&stats[0], vec);
-    atomicAdd((unsigned long long *)&stats[4], rec);
-    atomicAdd((unsigned long long *)&stats[3], mtile);
-    atomicAdd((unsigned long long *)&stats[12], mtile128);
+    s_seg[wave] = seg; s_item[wave] = item; s_run[wave] = run; s_tile[wave] = tile;
+    atomicAdd((unsigned long long *)&stats[0], v4[0]);
+    atomicAdd((unsigned long long *)&stats[4], v4[1]);
+    atomicAdd((unsigned long long *)&stats[3], v4[2]);
+    atomicAdd((unsigned long long *)&stats[12], v4[3]);
   }
   __syncthreads();
-  uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
+  uint32_t rs = 0, ri = 0, rr = 0, rt = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
   for (int w = 0; w < 16; ++w) {
-    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; wtile += s_tile[w]; }
+    if (w < wave) { rs += s_seg[w]; ri += s_item[w]; rr += s_run[w]; rt += s_tile[w]; }
     tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
   }
-  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
-  for (uint32_t l = beg; l < end; ++l) {
-    uint32_t segb;
-    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
-    seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
-    if (tile_start) tile_start[l] = rt;
-    const uint32_t c = cnt[l];
-    rs += c; ri += (group_chunks(c, qg)) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += (group_chunks(c, qg)) * ns * seg_records(segb);
+  for (uint32_t r0 = 0; r0 < rows; r0 += 8) {  // (the same values again, from L2 now)
+    uint32_t cs[8], lens[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t l = l_base + (r0 + u) * 64u + (uint32_t)lane;
+      const bool in = r0 + u < rows && l < nlists;
+      cs[u] = in ? cnt[l] : 0u;
+      lens[u] = in ? list_len[l] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      if (r0 + u >= rows) break;  // (wave-uniform)
+      const uint32_t l = l_base + (r0 + u) * 64u + (uint32_t)lane;
+      const PerList p = per_list(cs[u], lens[u], nullptr);
+      const uint32_t is = wave_incl_scan_u32(p.seg), ii = wave_incl_scan_u32(p.item);
+      const uint32_t ir = wave_incl_scan_u32(p.run), it = wave_incl_scan_u32(p.tile);
+      if (l < nlists) {
+        seg_start[l] = rs + is - p.seg; item_start[l] = ri + ii - p.item; segrun_start[l] = rr + ir - p.run;
+        if (tile_start) tile_start[l] = rt + it - p.tile;
+      }
+      rs += readlane_u(is, 63); ri += readlane_u(ii, 63); rr += readlane_u(ir, 63); rt += readlane_u(it, 63);
+    }
   }
   if (t == 0) {
     seg_start[nlists] = tseg;
