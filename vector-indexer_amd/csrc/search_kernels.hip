@@ -397,115 +397,13 @@ __global__ void cursor_kernel(const uint32_t *cnt, const uint32_t *seg_start, ui
   }
 }
 
-__global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
-                                                          uint32_t nlists, uint32_t qg, uint32_t segb0,
-                                                          uint32_t *seg_start, uint32_t *item_start,
-                                                          uint32_t *segrun_start, uint64_t *stats,
-                                                          uint32_t *tile_start) {
-  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
+// the scan over the lists shared by group_scan_kernel and group_prepare_kernel (one workgroup of 1024 threads)
+__device__ __forceinline__ void group_scan_lists(const uint32_t *cnt, const uint32_t *list_len, uint32_t nlists, uint32_t qg,
+                                                 uint32_t segb0, uint32_t *seg_start, uint32_t *item_start, uint32_t *segrun_start,
+                                                 uint64_t *stats, uint32_t *tile_start, uint32_t *s_seg, uint32_t *s_item,
+                                                 uint32_t *s_run, uint32_t *s_tile) {
   const uint32_t t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const uint32_t per = (nlists + 1023) / 1024;
-  const uint32_t beg = min(nlists, t * per), end = min(nlists, beg + per);
-  uint32_t seg = 0, item = 0, run = 0, tile = 0;
-  unsigned long long vec = 0, rec = 0, mtile = 0, mtile128 = 0;
-  for (uint32_t l = beg; l < end; ++l) {
-    const uint32_t c = cnt[l];  // (per-list totals: list_totals_kernel)
-    const uint32_t len = list_len[l];
-    uint32_t segb;
-    const uint32_t ns = list_segments(len, segb0, &segb);
-    const uint32_t chunks = group_chunks(c, qg);
-    seg += c;
-    item += chunks * ns;
-    run += ns > 1 ? c * ns : 0u;
-    vec += (unsigned long long)c * len;
-    mtile += (unsigned long long)chunks * ((len + 63) / 64);  // (query group, block) tiles ranked on the matrix cores
-    mtile128 += (unsigned long long)((c + 127) / 128) * ((len + 63) / 64);  // ... if the groups held 128 queries
-    tile += chunks * ns * seg_records(segb);  // record tiles of the MFMA engine (scan.hpp); count checked on the host
-    rec += 2ull * c * ns;
-  }
-  // inclusive scans across the wave, then across the 16 waves
-  uint32_t iseg = seg, iitem = item, irun = run, itile = tile;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t a = (uint32_t)__shfl_up((int)iseg, o), b = (uint32_t)__shfl_up((int)iitem, o);
-    const uint32_t r = (uint32_t)__shfl_up((int)irun, o), tt = (uint32_t)__shfl_up((int)itile, o);
-    if (lane >= o) { iseg += a; iitem += b; irun += r; itile += tt; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    vec += __shfl_xor(vec, o);
-    rec += __shfl_xor(rec, o);
-    mtile += __shfl_xor(mtile, o);
-    mtile128 += __shfl_xor(mtile128, o);
-  }
-  if (lane == 63) { s_seg[wave] = iseg; s_item[wave] = iitem; s_run[wave] = irun; s_tile[wave] = itile; }
-  if (lane == 0) {
-    atomicAdd((unsigned long long *)&stats[0], vec);  // scanned vectors
-    atomicAdd((unsigned long long *)&stats[4], rec);  // MFMA path: group records = 2 per (pair, segment)
-    atomicAdd((unsigned long long *)&stats[3], mtile);
-    atomicAdd((unsigned long long *)&stats[12], mtile128);
-  }
-  __syncthreads();
-  uint32_t wseg = 0, witem = 0, wrun = 0, wtile = 0, tseg = 0, titem = 0, trun = 0, ttile = 0;
-  for (int w = 0; w < 16; ++w) {
-    if (w < wave) { wseg += s_seg[w]; witem += s_item[w]; wrun += s_run[w]; wtile += s_tile[w]; }
-    tseg += s_seg[w]; titem += s_item[w]; trun += s_run[w]; ttile += s_tile[w];
-  }
-  uint32_t rs = wseg + iseg - seg, ri = witem + iitem - item, rr = wrun + irun - run, rt = wtile + itile - tile;
-  for (uint32_t l = beg; l < end; ++l) {
-    uint32_t segb;
-    const uint32_t ns = list_segments(list_len[l], segb0, &segb);
-    seg_start[l] = rs; item_start[l] = ri; segrun_start[l] = rr;
-    if (tile_start) tile_start[l] = rt;
-    const uint32_t c = cnt[l];
-    rs += c; ri += (group_chunks(c, qg)) * ns; rr += ns > 1 ? c * ns : 0u;
-    rt += (group_chunks(c, qg)) * ns * seg_records(segb);
-  }
-  if (t == 0) {
-    seg_start[nlists] = tseg;
-    item_start[nlists] = titem;
-    segrun_start[nlists] = trun;
-    stats[1] = titem;
-    stats[2] = trun;
-    stats[5] = ttile;  // pair-record tiles
-  }
-}
-
-// group_scan_kernel (workgroup 0) and the queries' record offsets (workgroup 1: exclusive scan of qtot, qoff[nq] = total)
-// in one launch: both are single-workgroup scans, independent of each other.  (Folding list_totals and cursor in as well —
-// one workgroup reading all 32 sub-bins of every list twice — was measured: the grouping took twice as long.)
-__global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt, const uint32_t *list_len, uint32_t nlists, uint32_t qg,
-                                                             uint32_t segb0, uint32_t *seg_start, uint32_t *item_start,
-                                                             uint32_t *segrun_start, uint64_t *stats, uint32_t *tile_start,
-                                                             const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
-  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
-  const uint32_t t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  if (blockIdx.x == 1) {  // ---- query offsets ----
-    if (!qtot) return;
-    const uint32_t per = (nq + 1023) / 1024;
-    const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
-    uint32_t sum = 0;
-    for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
-    uint32_t inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
-      if (lane >= o) inc += x;
-    }
-    if (lane == 63) s_seg[wave] = inc;
-    __syncthreads();
-    uint32_t w = 0, tot = 0;
-    for (int i = 0; i < 16; ++i) {
-      if (i < wave) w += s_seg[i];
-      tot += s_seg[i];
-    }
-    uint32_t run = w + inc - sum;
-    for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
-    if (t == 0) qoff[nq] = tot;
-    return;
-  }
   // ---- lists (cnt = the per-list totals of list_totals_kernel, which also reset the counters added to below) ----
   // Wave w owns the contiguous lists [w R 64, (w + 1) R 64) as R rows of 64, a lane per list: every load and store is one
   // coalesced instruction, eight rows' loads in flight together.  (A thread walking its own 64 lists — 65 536 lists — read
@@ -594,6 +492,52 @@ __global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt
     stats[2] = trun;
     stats[5] = ttile;
   }
+}
+
+__global__ void __launch_bounds__(1024) group_scan_kernel(const uint32_t *cnt, const uint32_t *list_len,
+                                                          uint32_t nlists, uint32_t qg, uint32_t segb0,
+                                                          uint32_t *seg_start, uint32_t *item_start,
+                                                          uint32_t *segrun_start, uint64_t *stats,
+                                                          uint32_t *tile_start) {
+  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
+  group_scan_lists(cnt, list_len, nlists, qg, segb0, seg_start, item_start, segrun_start, stats, tile_start, s_seg, s_item, s_run, s_tile);
+}
+
+// group_scan_kernel (workgroup 0) and the queries' record offsets (workgroup 1: exclusive scan of qtot, qoff[nq] = total)
+// in one launch: both are single-workgroup scans, independent of each other.  (Folding list_totals and cursor in as well —
+// one workgroup reading all 32 sub-bins of every list twice — was measured: the grouping took twice as long.)
+__global__ void __launch_bounds__(1024) group_prepare_kernel(const uint32_t *cnt, const uint32_t *list_len, uint32_t nlists, uint32_t qg,
+                                                             uint32_t segb0, uint32_t *seg_start, uint32_t *item_start,
+                                                             uint32_t *segrun_start, uint64_t *stats, uint32_t *tile_start,
+                                                             const uint32_t *qtot, uint32_t nq, uint32_t *qoff) {
+  __shared__ uint32_t s_seg[16], s_item[16], s_run[16], s_tile[16];
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  if (blockIdx.x == 1) {  // ---- query offsets ----
+    if (!qtot) return;
+    const uint32_t per = (nq + 1023) / 1024;
+    const uint32_t beg = min(nq, t * per), end = min(nq, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; ++i) sum += qtot[i];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= o) inc += x;
+    }
+    if (lane == 63) s_seg[wave] = inc;
+    __syncthreads();
+    uint32_t w = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) {
+      if (i < wave) w += s_seg[i];
+      tot += s_seg[i];
+    }
+    uint32_t run = w + inc - sum;
+    for (uint32_t i = beg; i < end; ++i) { qoff[i] = run; run += qtot[i]; }
+    if (t == 0) qoff[nq] = tot;
+    return;
+  }
+  group_scan_lists(cnt, list_len, nlists, qg, segb0, seg_start, item_start, segrun_start, stats, tile_start, s_seg, s_item, s_run, s_tile);
 }
 
 // (list ids are range-checked wherever they index: a caller-supplied probe list, vi_indexer_search_probed_device, is
