@@ -1733,7 +1733,7 @@ struct CoarseSelectArgs {
   uint32_t list_segb0;
   uint32_t *rel, *qtot;
   uint32_t staged;  // single rows fetched by the whole wave through LDS (exact_batch_rows_staged_fn); VI_COARSE_STAGED=0: a row per lane
-  uint32_t *pair_rank;  // direct kernel: where the pair stands among the pairs of its (list, sub-bin) — the value its histogram
+  uint32_t *pair_rank;  // where the pair stands among the pairs of its (list, sub-bin) — the value its histogram
                         // increment returns — so that the grouping's scatter needs no atomics of its own; or null
 };
 
@@ -1760,7 +1760,10 @@ __global__ void __launch_bounds__(256, 4) coarse_select_kernel(CoarseSelectArgs 
   if ((uint32_t)lane < a.P) {
     a.probes[(size_t)q * a.P + lane] = mylist;
     a.gorder[(size_t)q * a.P + lane] = g;
-    if (mylist != kNoPos && a.list_len[mylist] > 0) atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
+    if (mylist != kNoPos && a.list_len[mylist] > 0) {
+      const uint32_t before = atomicAdd(&a.cnt[subbin_index(mylist, q & (kSubBins - 1), a.nlists)], 1u);
+      if (a.pair_rank) a.pair_rank[(size_t)q * a.P + lane] = before;
+    }
   }
   // group records of the list phase: 2 per (probe, segment); query_offsets_kernel turns the per-query totals
   // into offsets
@@ -2426,7 +2429,7 @@ vi_status stage_coarse_filter(const DeviceIndex &ix, const float *Qd, uint64_t n
     { const char *e = getenv("VI_COARSE_STAGED"); a.staged = (e && *e == '0') || (ix.dim & 15u) ? 0u : 1u; }
     {
       const char *e = getenv("VI_SCATTER_RANKED");
-      ws.pair_rank_valid = direct && !(e && *e == '0');
+      ws.pair_rank_valid = !(e && *e == '0');  // (both coarse selects keep what their histogram increment returns)
       if (ws.pair_rank_valid) { VI_TRY(ws.pair_rank.reserve(nq * P)); a.pair_rank = ws.pair_rank.p; }
     }
     { const char *e = getenv("VI_FILTER_STATS"); if (!(e && *e == '2')) a.c.dbg = nullptr; }  // '2': count the coarse step
